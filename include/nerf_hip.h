@@ -1,0 +1,137 @@
+/*
+ * nerf_hip.h -- C ABI of libnerf_hip.so, the MI355X (gfx950) volume-rendering hot path.
+ *
+ * The reference (D-Hank/NeRF-tiny) has no FFI: its boundary for this path is the Python
+ * method surface of NeRFModel (nerf.py:170 ctor, nerf.py:333-348 forward, nerf.py:325-331
+ * ray_loss, autograd backward at nerf.py:473).  Each entry point below replaces the cited
+ * span of nerf.py; INTEGRATION.md shows the ctypes stub a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / HIP C++ types.  `stream` is a hipStream_t passed
+ *     as void* (NULL = default stream).  Every call only ENQUEUES work on `stream`; no call
+ *     synchronises with the host except nerf_hip_read_status().
+ *   - ownership: the caller allocates every buffer (device unless marked HOST) including the
+ *     workspace; the library allocates nothing persistent and frees nothing.
+ *   - errors: 0 = NERF_HIP_OK, negative = error; nerf_hip_last_error() gives the text
+ *     (thread-local).  The library never aborts the process.
+ *   - threading: re-entrant per (device, stream); calls sharing a workspace must be ordered
+ *     on one stream.
+ *   - all floating point data is IEEE fp32 ("f32"), row-major.
+ *
+ * Weight order (`weights24`, HOST array of 24 DEVICE pointers) = NeRFModel.network.parameters()
+ * order, nn.Linear layout [out, in] (nerf.py:85-99):
+ *    0..15  point_layer[i].0.{weight,bias}  i = 0..7   W0[256,60] W1-3[256,256] W4[256,316] W5-7[256,256]
+ *   16,17   sigma_layer.0.{weight[1,256],bias[1]}
+ *   18,19   point_info.{weight[256,256],bias[256]}
+ *   20,21   dir_info.0.{weight[128,280],bias[128]}
+ *   22,23   color_layer.0.{weight[3,128],bias[3]}
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_HIP_ABI_VERSION 1
+
+enum {
+  NERF_HIP_OK = 0,
+  NERF_HIP_ERR_ARG = -1,       /* bad shape / null pointer / unsupported size        */
+  NERF_HIP_ERR_WORKSPACE = -2, /* workspace too small for (B, Nc, Nf, flags)          */
+  NERF_HIP_ERR_DEVICE = -3,    /* a HIP runtime call failed (text in last_error)      */
+  NERF_HIP_ERR_ARCH = -4       /* device is not gfx950                                */
+};
+
+/* flags */
+enum {
+  NERF_HIP_SAVE_FOR_BACKWARD = 1 << 0, /* forward keeps activations in the workspace for nerf_hip_backward */
+};
+
+/* status word bits (nerf_hip_read_status) */
+enum {
+  NERF_HIP_STATUS_RESAMPLE_INDEX = 1 << 0, /* the condition on which nerf.py:251-253 calls exit(0) (quirk Q7) */
+};
+
+/* Limits of this build: 2 <= B, 2 <= Nc <= 1024, 1 <= Nf <= 1024, Nc + Nf <= 2048. */
+
+int nerf_hip_abi_version(void);
+const char* nerf_hip_last_error(void);
+
+/* Bytes of device workspace nerf_hip_forward / nerf_hip_backward need for these sizes. */
+int nerf_hip_ws_bytes(int B, int Nc, int Nf, int flags, size_t* bytes);
+
+/*
+ * Whole forward: replaces NeRFModel.forward -> render_rays (nerf.py:333-348, 286-323).
+ *   row, col        [B] i64   pixel coordinates; x <- row, y <- col (nerf.py:186-188)
+ *   poses_bound     [B,17] f32  rows as loader.py:33: 3x5 [R|o|hwf] then near, far (already cast, nerf.py:338)
+ *   K_inv9          HOST [9] f32, the matrix passed to forward (already transposed, nerf.py:433)
+ *   ray0_near_far   HOST [2] f32 or NULL.  The slope of the inverse CDF uses the coarse spacing of
+ *                   RAY 0 OF THE BATCH for every ray (nerf.py:233); a caller that shards one batch
+ *                   over several GPUs passes the global ray 0's (near, far) here; NULL = this call's ray 0.
+ *   last_delta      nerf.py:286 `last` (1e-4)
+ *   C_coarse,C_fine [B,3] f32 out
+ *   ws              workspace of >= nerf_hip_ws_bytes(B,Nc,Nf,flags) bytes, 256-byte aligned
+ */
+int nerf_hip_forward(const float* const* weights24, const int64_t* row, const int64_t* col,
+                     const float* poses_bound, const float* K_inv9, const float* ray0_near_far,
+                     int B, int Nc, int Nf, float last_delta, float* C_coarse, float* C_fine,
+                     void* ws, size_t ws_bytes, int flags, void* stream);
+
+/*
+ * Backward of nerf_hip_forward (autograd through nerf.py:286-323, called at nerf.py:473).
+ * Needs the workspace of a forward run with NERF_HIP_SAVE_FOR_BACKWARD and the same sizes/inputs.
+ *   dC_coarse, dC_fine [B,3] f32   upstream gradients
+ *   dweights24         HOST array of 24 DEVICE pointers, same shapes as weights24; OVERWRITTEN with
+ *                      the gradients of this batch (sum over rays, no averaging)
+ */
+int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, const float* dC_fine,
+                      int B, int Nc, int Nf, float last_delta, float* const* dweights24,
+                      void* ws, size_t ws_bytes, int flags, void* stream);
+
+/* ray_loss (nerf.py:325-331) and its gradient: loss[1] = sum (C_c-C*)^2 + sum (C_f-C*)^2,
+ * dC_c = 2 (C_c - C*), dC_f = 2 (C_f - C*).  dC_* may be NULL. */
+int nerf_hip_ray_loss(const float* C_coarse, const float* C_fine, const float* C_true, int B,
+                      float* loss, float* dC_coarse, float* dC_fine, void* stream);
+
+/* Copies the status word of the last forward on this workspace to the host (synchronises `stream`). */
+int nerf_hip_read_status(const void* ws, size_t ws_bytes, uint32_t* status, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage entry points (same kernels as nerf_hip_forward; exposed so each row of the hot-path
+ * table can be parity-checked on its own).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Ray generation (nerf.py:52-67, 186-197, 211, 288): per ray d_cam[B,3], d_wrd[B,3], t_coarse[B,Nc]. */
+int nerf_hip_rays(const int64_t* row, const int64_t* col, const float* poses_bound, const float* K_inv9,
+                  int B, int Nc, float* d_cam, float* d_wrd, float* t_coarse, void* stream);
+
+/* Field query (nerf.py:200-219 + Encoder 135-167 + Network 101-124) at depths t[B,N]:
+ * rgb[B,N,3], sigma[B,N]; optional debug outputs pts[B,N,3], gamma_p[B,N,60] (may be NULL).
+ * ws: >= nerf_hip_ws_bytes(B, N, N, 0). */
+int nerf_hip_field(const float* const* weights24, const int64_t* row, const int64_t* col,
+                   const float* poses_bound, const float* K_inv9, const float* t, int B, int N,
+                   float* rgb, float* sigma, float* pts, float* gamma_p,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* Coarse weights, colour and inverse-CDF resampling (nerf.py:263-281, 293-295, 225-261, 320):
+ * in t_c, sigma_c [B,Nc], rgb_c [B,Nc,3], near_far [B,2]; out w_c [B,Nc], C_coarse [B,3], t_f [B,Nf],
+ * status[1] u32 (OR-ed).  delta0 = coarse spacing used in the slope (HOST value). */
+int nerf_hip_coarse_composite(const float* t_c, const float* sigma_c, const float* rgb_c, const float* near_far,
+                              float delta0, int B, int Nc, int Nf, float* w_c, float* C_coarse, float* t_f,
+                              uint32_t* status, void* stream);
+
+/* Merge + per-channel sort + composite (nerf.py:302-321): in t_c/t_f, sigma_c/sigma_f, rgb_c/rgb_f;
+ * out sorted bundle[B,Nc+Nf,5] (t,r,g,b,sigma; may be NULL), w[B,Nc+Nf] (may be NULL), C_fine[B,3]. */
+int nerf_hip_merge_composite(const float* t_c, const float* t_f, const float* sigma_c, const float* sigma_f,
+                             const float* rgb_c, const float* rgb_f, int B, int Nc, int Nf, float last_delta,
+                             float* bundle, float* w, float* C_fine, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

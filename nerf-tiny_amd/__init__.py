@@ -1,0 +1,7 @@
+"""MI355X-native NeRF volume-rendering hot path (drop-in for D-Hank/NeRF-tiny's NeRFModel).
+
+Layout:  csrc/ (HIP kernels + C ABI -> libnerf_hip.so), _abi.py (ctypes binding),
+nerf.py (host-side mirror of the reference's ``nerf`` module surface), ops.py (stage-level calls).
+"""
+from . import _abi, ops  # noqa: F401
+from .nerf import NeRFModel, Network, Encoder  # noqa: F401

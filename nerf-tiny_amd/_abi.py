@@ -1,0 +1,79 @@
+"""ctypes binding of libnerf_hip.so (include/nerf_hip.h).
+
+The library is the product: if it is missing or does not export a declared symbol this module
+raises -- there is no CPU or eager-PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerf_hip.so")
+
+NERF_HIP_ABI_VERSION = 1
+SAVE_FOR_BACKWARD = 1 << 0
+STATUS_RESAMPLE_INDEX = 1 << 0
+
+_p = C.c_void_p
+_PROTOS = {
+    "nerf_hip_abi_version": (C.c_int, []),
+    "nerf_hip_last_error": (C.c_char_p, []),
+    "nerf_hip_ws_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "nerf_hip_forward": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, C.c_size_t, C.c_int, _p]),
+    "nerf_hip_backward": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_size_t, C.c_int, _p]),
+    "nerf_hip_ray_loss": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, _p]),
+    "nerf_hip_read_status": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_uint32), _p]),
+    "nerf_hip_rays": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p]),
+    "nerf_hip_field": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_size_t, _p]),
+    "nerf_hip_coarse_composite": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
+    "nerf_hip_merge_composite": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, _p]),
+}
+EXPORTS = tuple(_PROTOS)
+
+_lib = None
+
+
+class NerfHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Loads libnerf_hip.so once.  Raises if it is absent (run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NerfHipError(f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}`; "
+                               "this package has no fallback path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if L.nerf_hip_abi_version() != NERF_HIP_ABI_VERSION:
+            raise NerfHipError("libnerf_hip.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise NerfHipError(f"libnerf_hip error {rc}: {lib().nerf_hip_last_error().decode()}")
+
+
+def ws_bytes(B: int, Nc: int, Nf: int, flags: int) -> int:
+    n = C.c_size_t(0)
+    check(lib().nerf_hip_ws_bytes(B, Nc, Nf, flags, C.byref(n)))
+    return int(n.value)
+
+
+def ptr_array(tensors) -> "C.Array":
+    """HOST array of device pointers (weights24 / dweights24)."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def f32_array(values) -> "C.Array":
+    return (C.c_float * len(values))(*[float(v) for v in values])

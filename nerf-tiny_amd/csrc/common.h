@@ -1,0 +1,69 @@
+// common.h -- shared constants, workspace layout and kernel argument blocks of libnerf_hip.so.
+// MI355X / gfx950 only.  Reference citations are to /root/reference/nerf.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nerf {
+
+constexpr int WIDTH = 256;      // nerf.py:76
+constexpr int POINT_DIM = 60;   // 3 * 2 * L_point (nerf.py:127, :103)
+constexpr int DIR_DIM = 24;     // 3 * 2 * L_dir
+constexpr int L_POINT = 10;
+constexpr int L_DIR = 4;
+constexpr int HALF = 128;       // width of the colour branch (nerf.py:98)
+constexpr int TM = 64;          // samples per workgroup tile of the field kernels
+constexpr int RAYF = 24;        // floats per ray record
+
+// Ray record (one per ray, written by k_rays):
+//  [0..8] R row-major  [9..11] o  [12..14] d_cam  [15..17] d_wrd  [18] near  [19] far
+//  [20] (far-near)/(Nc-1)  [21] (far-near)/Nc  [22..23] pad
+enum { RF_R = 0, RF_O = 9, RF_DCAM = 12, RF_DWRD = 15, RF_NEAR = 18, RF_FAR = 19, RF_STEP = 20, RF_DELTA = 21 };
+
+// ---- packed weight segments (MFMA fragment order, see pack kernel in field_fwd.hip) ----
+// A segment holds W[nft*32 features][KB*8 inputs] as float4[nft][KB][64 lanes]:
+//   lane l, component s  =  W[ft*32 + (l&31)][kb*8 + 4*(l>>5) + s]     (0 beyond the real K)
+struct Seg { int off4; int nft; int kb; };  // off4 in float4 units
+// forward segments
+constexpr int SEG_L0 = 0, SEG_L1 = 1, SEG_L2 = 2, SEG_L3 = 3, SEG_L4A = 4, SEG_L4B = 5, SEG_L5 = 6, SEG_L6 = 7,
+              SEG_L7 = 8, SEG_PI = 9, SEG_DIR = 10, NSEG_FWD = 11;
+// transposed segments for the backward dX chain (features <-> inputs swapped)
+constexpr int SEG_T_DIR = 11, SEG_T_PI = 12, SEG_T_L7 = 13, SEG_T_L6 = 14, SEG_T_L5 = 15, SEG_T_L4A = 16, SEG_T_L4B = 17,
+              SEG_T_L3 = 18, SEG_T_L2 = 19, SEG_T_L1 = 20, SEG_T_L0 = 21, NSEG = 22;
+
+__host__ __device__ constexpr int seg_nft(int s) {
+  return (s == SEG_DIR) ? 4 : (s <= SEG_PI) ? 8 : (s == SEG_T_L4B || s == SEG_T_L0) ? 2 : 8;
+}
+__host__ __device__ constexpr int seg_kb(int s) {
+  return (s == SEG_L0 || s == SEG_L4B) ? 8 : (s <= SEG_DIR) ? 32 : (s == SEG_T_DIR) ? 16 : 32;
+}
+__host__ __device__ constexpr int seg_off4(int s) {
+  int o = 0;
+  for (int i = 0; i < s; ++i) o += seg_nft(i) * seg_kb(i) * 64;
+  return o;
+}
+constexpr int PACKED_FWD_F4 = seg_off4(NSEG_FWD);
+constexpr int PACKED_ALL_F4 = seg_off4(NSEG);
+
+// positional-encoding frequencies f_l = fp32(2^e_l)*fp32(pi), e = linspace(0,L,L) (nerf.py:141-146, quirk Q3);
+// bit patterns as produced by torch 2.10 (tests/golden/make_golden.py prints them; tests/test_oracle_golden.py pins them).
+__device__ __constant__ const uint32_t kFreqPointBits[10] = {0x40490fdbu, 0x40d928aeu, 0x416a8b6cu, 0x41fd527bu, 0x4288cd33u,
+                                                             0x4313c0fau, 0x439f953cu, 0x442c5befu, 0x44ba2881u, 0x45490fdbu};
+__device__ __constant__ const uint32_t kFreqDirBits[4] = {0x40490fdbu, 0x40fd527au, 0x419f953cu, 0x42490fdbu};
+
+// weights24 indices
+enum { W_L0 = 0, B_L0 = 1, W_SIGMA = 16, B_SIGMA = 17, W_PI = 18, B_PI = 19, W_DIR = 20, B_DIR = 21, W_COLOR = 22, B_COLOR = 23 };
+
+struct Weights24 { const float* p[24]; };
+struct Grads24 { float* p[24]; };
+
+// ---- workspace carve-up (host side, api.cpp) ----
+struct WsLayout {
+  size_t status, packed, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
+  // training-only
+  size_t perm, w_m, bundle, save_c, save_f, spre_c, spre_f, gbuf;
+  size_t total;
+};
+
+}  // namespace nerf

@@ -1,0 +1,417 @@
+// field_fwd.hip -- fused field query for MI355X (gfx950): sample point -> positional encoding ->
+// 8x256 MLP (+ sigma / feature / direction / colour heads) for a tile of 64 samples per workgroup.
+//
+// Replaces, per sample: nerf.py:200-216 (world point), Encoder.forward nerf.py:135-167,
+// Network.forward nerf.py:101-124.
+//
+// Design:
+//  * one workgroup = 256 threads = 4 waves owns 64 samples; their activations [64][256] f32 live in
+//    LDS for the whole network (row stride 260 floats: conflict-free ds_read_b128 / ds_write_b128);
+//  * every 256-wide layer is computed as  D[feature][sample] = W[feature][k] * act[sample][k]  with
+//    v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain): the WEIGHTS are the A operand, the
+//    activations the B operand, so a lane's 16 accumulators are 4x4 consecutive features of ONE
+//    sample and go back to LDS as four 16-byte stores, already in the layout the next layer reads;
+//  * wave w owns features [64w, 64w+64) x 64 samples = 2x2 MFMA tiles (64 accumulator VGPRs);
+//  * weights are pre-packed in fragment order (k_pack_weights) so a lane fetches 4 k-steps of its
+//    A fragment with ONE coalesced 16-byte global load (1 KiB per wave instruction, L2 resident:
+//    all 2.36 MB of weights fit every XCD's 4 MiB L2); the next k-block's fragment is prefetched
+//    behind the current block's 16 MFMAs (1024 cycles), which hides the L2 latency;
+//  * two workgroups per CU (2 x 68 KiB LDS): one's barriers/epilogues hide under the other's MFMAs.
+#include "kernels.h"
+
+namespace nerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+
+// ------------------------------------------------------------------------------------------
+// weight packing: raw nn.Linear [out][in] -> MFMA A-fragment order, forward and transposed.
+// ------------------------------------------------------------------------------------------
+struct PackDesc { int src; int ld; int col0; int rows; int cols; int transposed; };
+// element (feature f, input k) of segment s:
+//   forward:     W[src][f][col0 + k]           f < rows, k < cols
+//   transposed:  W[src][k][col0 + f]           f < cols(of slice) ...
+__device__ __forceinline__ PackDesc pack_desc(int s) {
+  switch (s) {
+    case SEG_L0: return {0, 60, 0, 256, 60, 0};
+    case SEG_L1: return {2, 256, 0, 256, 256, 0};
+    case SEG_L2: return {4, 256, 0, 256, 256, 0};
+    case SEG_L3: return {6, 256, 0, 256, 256, 0};
+    case SEG_L4A: return {8, 316, 0, 256, 256, 0};
+    case SEG_L4B: return {8, 316, 256, 256, 60, 0};
+    case SEG_L5: return {10, 256, 0, 256, 256, 0};
+    case SEG_L6: return {12, 256, 0, 256, 256, 0};
+    case SEG_L7: return {14, 256, 0, 256, 256, 0};
+    case SEG_PI: return {W_PI, 256, 0, 256, 256, 0};
+    case SEG_DIR: return {W_DIR, 280, 24, 128, 256, 0};
+    // transposed: rows = number of output features of the transposed product (= inputs of the layer),
+    // cols = reduction length (= outputs of the layer)
+    case SEG_T_DIR: return {W_DIR, 280, 24, 256, 128, 1};
+    case SEG_T_PI: return {W_PI, 256, 0, 256, 256, 1};
+    case SEG_T_L7: return {14, 256, 0, 256, 256, 1};
+    case SEG_T_L6: return {12, 256, 0, 256, 256, 1};
+    case SEG_T_L5: return {10, 256, 0, 256, 256, 1};
+    case SEG_T_L4A: return {8, 316, 0, 256, 256, 1};
+    case SEG_T_L4B: return {8, 316, 256, 60, 256, 1};
+    case SEG_T_L3: return {6, 256, 0, 256, 256, 1};
+    case SEG_T_L2: return {4, 256, 0, 256, 256, 1};
+    case SEG_T_L1: return {2, 256, 0, 256, 256, 1};
+    default: return {0, 60, 0, 60, 256, 1};  // SEG_T_L0
+  }
+}
+
+__global__ void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg) {
+  // one thread per float4 of the packed image
+  const int total = seg_off4(nseg);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int s = 0;
+#pragma unroll 1
+    while (s + 1 < nseg && idx >= seg_off4(s + 1)) ++s;
+    const int local = idx - seg_off4(s);
+    const int kbn = seg_kb(s);
+    const int lane = local & 63;
+    const int kb = (local >> 6) % kbn;
+    const int ft = (local >> 6) / kbn;
+    const PackDesc d = pack_desc(s);
+    const float* W = w.p[d.src];
+    const int f = ft * 32 + (lane & 31);
+    const int k0 = kb * 8 + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + c;
+      float x = 0.f;
+      if (f < d.rows && k < d.cols) x = d.transposed ? W[(size_t)k * d.ld + d.col0 + f] : W[(size_t)f * d.ld + d.col0 + k];
+      v[c] = x;
+    }
+    out[idx] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// building blocks of the fused kernels
+// ------------------------------------------------------------------------------------------
+
+// acc[f][st] += W[ft0+f tile][k] * act[st*32 + sample][k]  for k in [0, 8*KB)
+template <int KB, int NFT>
+__device__ __forceinline__ void mfma_layer(const float4* __restrict__ wseg, int ft0, const float* act, int kcol0, int lane,
+                                           f32x16 (&acc)[NFT][2]) {
+  const int j = lane & 31, h = lane >> 5;
+  const float* a0p = act + j * LDA + kcol0 + 4 * h;
+  const float* a1p = a0p + 32 * LDA;
+  const float4* wbase = wseg + (size_t)ft0 * KB * 64 + lane;
+  float4 wc[NFT], wn[NFT];
+#pragma unroll
+  for (int f = 0; f < NFT; ++f) wc[f] = wbase[(size_t)f * KB * 64];
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    const int kn = (kb + 1 < KB) ? kb + 1 : kb;
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) wn[f] = wbase[(size_t)(f * KB + kn) * 64];
+    const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
+    const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) {
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].x, a0.x, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].x, a1.x, acc[f][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) {
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].y, a0.y, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].y, a1.y, acc[f][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) {
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].z, a0.z, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].z, a1.z, acc[f][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) {
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].w, a0.w, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].w, a1.w, acc[f][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) wc[f] = wn[f];
+  }
+}
+
+// accumulators <- bias (feature = fbase + f*32 + 8g + 4h + r for register 4g + r)
+template <int NFT>
+__device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, int fbase, int lane, f32x16 (&acc)[NFT][2]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int f = 0; f < NFT; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + fbase + f * 32 + 8 * g + 4 * h);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        acc[f][st][4 * g + 0] = b.x;
+        acc[f][st][4 * g + 1] = b.y;
+        acc[f][st][4 * g + 2] = b.z;
+        acc[f][st][4 * g + 3] = b.w;
+      }
+    }
+}
+
+// accumulators -> LDS activation rows (optionally through ReLU)
+template <int NFT, bool RELU>
+__device__ __forceinline__ void acc_store(float* act, int fbase, int lane, const f32x16 (&acc)[NFT][2]) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int f = 0; f < NFT; ++f)
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(acc[f][st][4 * g], acc[f][st][4 * g + 1], acc[f][st][4 * g + 2], acc[f][st][4 * g + 3]);
+        if (RELU) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(act + (st * 32 + j) * LDA + fbase + f * 32 + 8 * g + 4 * h) = v;
+      }
+}
+
+// world point of a sample: v = d_cam * t; p = ((R0*v0 + R1*v1) + R2*v2) + o   (nerf.py:200-216; every product
+// and sum rounded separately -- the translation unit is built with -ffp-contract=off)
+__device__ __forceinline__ void sample_point(const float* __restrict__ rf, float t, float (&p)[3]) {
+  const float v0 = rf[RF_DCAM + 0] * t, v1 = rf[RF_DCAM + 1] * t, v2 = rf[RF_DCAM + 2] * t;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) p[c] = ((rf[RF_R + 3 * c] * v0 + rf[RF_R + 3 * c + 1] * v1) + rf[RF_R + 3 * c + 2] * v2) + rf[RF_O + c];
+}
+
+// gamma_p of this thread's sample -> act[sm][0..63] (cols 60..63 = 0).  Wave wv writes (c,l) pairs 8wv .. 8wv+7.
+// gamma[c*20 + 2l + s] = (sin, cos)[s](fp32(x_c * f_l))   (nerf.py:135-167, flatten nerf.py:103)
+__device__ __forceinline__ void encode_point_to_lds(const float (&p)[3], float* act, int sm, int wv) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = wv * 8 + i;  // wave-uniform
+    float2 sc = make_float2(0.f, 0.f);
+    int col;
+    if (e < 30) {
+      const int c = e / 10, l = e - 10 * c;
+      const float x = (c == 0) ? p[0] : ((c == 1) ? p[1] : p[2]);
+      const float ph = x * __uint_as_float(kFreqPointBits[l]);
+      sc.x = sinf(ph);
+      sc.y = cosf(ph);
+      col = c * 20 + 2 * l;
+    } else {
+      col = 60 + 2 * (e - 30);
+    }
+    *reinterpret_cast<float2*>(act + sm * LDA + col) = sc;
+  }
+}
+
+// copy act[0..63][0..ncol) to a row-major global buffer dst[m0 + r][ldd]
+__device__ __forceinline__ void save_rows(const float* act, float* __restrict__ dst, int m0, int M, int ncol4, int ldd, int tid) {
+  // ncol4 = columns / 4 (64 or 32); threads sweep rows
+  const int per_row = ncol4;
+  for (int idx = tid; idx < TM * per_row; idx += 256) {
+    const int r = idx / per_row, c4 = idx - r * per_row;
+    if (m0 + r < M) {
+      const float4 v = *reinterpret_cast<const float4*>(act + r * LDA + 4 * c4);
+      *reinterpret_cast<float4*>(dst + (size_t)(m0 + r) * ldd + 4 * c4) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// the fused forward kernel
+// ------------------------------------------------------------------------------------------
+template <bool SAVE>
+__global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem;
+  float* scr = smem + TM * LDA;  // [4][64][3]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m0 = blockIdx.x * TM;
+  const int sm = lane;  // sample handled by this thread in the per-sample (VALU) stages
+  const int m = m0 + sm;
+  const bool valid = m < a.M;
+  const int mc = valid ? m : a.M - 1;
+  const int ray = mc / a.N;
+  const float* rf = a.rayf + (size_t)ray * RAYF;
+
+  float p[3];
+  sample_point(rf, a.t[mc], p);
+  if (a.pts_dbg && valid && wv == 0) {
+    a.pts_dbg[(size_t)m * 3 + 0] = p[0];
+    a.pts_dbg[(size_t)m * 3 + 1] = p[1];
+    a.pts_dbg[(size_t)m * 3 + 2] = p[2];
+  }
+  encode_point_to_lds(p, act, sm, wv);
+  __syncthreads();
+  if (a.gp_dbg) {
+    for (int idx = tid; idx < TM * POINT_DIM; idx += 256) {
+      const int r = idx / POINT_DIM, c = idx - r * POINT_DIM;
+      if (m0 + r < a.M) a.gp_dbg[(size_t)(m0 + r) * POINT_DIM + c] = act[r * LDA + c];
+    }
+  }
+
+  f32x16 acc[2][2];
+  const int fbase = wv * 64;
+  const size_t MS = (size_t)a.M * WIDTH;  // stride between saved layers
+
+  // ---- layer 0: 60(64) -> 256
+  acc_init_bias<2>(a.w.p[B_L0], fbase, lane, acc);
+  mfma_layer<8, 2>(a.wp + seg_off4(SEG_L0), wv * 2, act, 0, lane, acc);
+  __syncthreads();
+  acc_store<2, true>(act, fbase, lane, acc);
+  __syncthreads();
+  if (SAVE) save_rows(act, a.save + 0 * MS, m0, a.M, 64, WIDTH, tid);
+
+  // ---- layers 1..3
+#pragma unroll 1
+  for (int l = 1; l <= 3; ++l) {
+    acc_init_bias<2>(a.w.p[2 * l + 1], fbase, lane, acc);
+    mfma_layer<32, 2>(a.wp + seg_off4(SEG_L0) + seg_nft(SEG_L0) * seg_kb(SEG_L0) * 64 + (size_t)(l - 1) * 8 * 32 * 64, wv * 2, act, 0,
+                      lane, acc);
+    __syncthreads();
+    acc_store<2, true>(act, fbase, lane, acc);
+    __syncthreads();
+    if (SAVE) save_rows(act, a.save + (size_t)l * MS, m0, a.M, 64, WIDTH, tid);
+  }
+
+  // ---- layer 4: cat(h3, gamma_p) (hidden first, nerf.py:109) -> 256
+  acc_init_bias<2>(a.w.p[9], fbase, lane, acc);
+  mfma_layer<32, 2>(a.wp + seg_off4(SEG_L4A), wv * 2, act, 0, lane, acc);
+  __syncthreads();
+  encode_point_to_lds(p, act, sm, wv);  // re-encode into the (now free) activation buffer
+  __syncthreads();
+  mfma_layer<8, 2>(a.wp + seg_off4(SEG_L4B), wv * 2, act, 0, lane, acc);
+  __syncthreads();
+  acc_store<2, true>(act, fbase, lane, acc);
+  __syncthreads();
+  if (SAVE) save_rows(act, a.save + 4 * MS, m0, a.M, 64, WIDTH, tid);
+
+  // ---- layers 5..7
+#pragma unroll 1
+  for (int l = 5; l <= 7; ++l) {
+    acc_init_bias<2>(a.w.p[2 * l + 1], fbase, lane, acc);
+    mfma_layer<32, 2>(a.wp + seg_off4(SEG_L5) + (size_t)(l - 5) * 8 * 32 * 64, wv * 2, act, 0, lane, acc);
+    __syncthreads();
+    acc_store<2, true>(act, fbase, lane, acc);
+    __syncthreads();
+    if (SAVE) save_rows(act, a.save + (size_t)l * MS, m0, a.M, 64, WIDTH, tid);
+  }
+
+  // ---- sigma head (VALU): sigma = |w_sigma . h7 + b|   (nerf.py:94, 115)
+  {
+    const float* ws = a.w.p[W_SIGMA] + wv * 64;
+    const float* hr = act + sm * LDA + wv * 64;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(hr + k);
+      s = __builtin_fmaf(hv.x, ws[k], s);
+      s = __builtin_fmaf(hv.y, ws[k + 1], s);
+      s = __builtin_fmaf(hv.z, ws[k + 2], s);
+      s = __builtin_fmaf(hv.w, ws[k + 3], s);
+    }
+    scr[wv * 64 + sm] = s;
+  }
+
+  // ---- point_info: 256 -> 256, no activation (nerf.py:96, 117)
+  acc_init_bias<2>(a.w.p[B_PI], fbase, lane, acc);
+  mfma_layer<32, 2>(a.wp + seg_off4(SEG_PI), wv * 2, act, 0, lane, acc);
+  __syncthreads();
+  if (wv == 0 && valid) {
+    const float pre = ((scr[sm] + scr[64 + sm]) + (scr[128 + sm] + scr[192 + sm])) + a.w.p[B_SIGMA][0];
+    a.sigma[m] = fabsf(pre);
+    if (SAVE) a.spre[m] = pre;
+  }
+  acc_store<2, false>(act, fbase, lane, acc);
+  __syncthreads();
+  if (SAVE) save_rows(act, a.save + 8 * MS, m0, a.M, 64, WIDTH, tid);
+
+  // ---- dir_info: cat(gamma_d, feat) -> 128, ReLU (nerf.py:98, 118).  The gamma_d part (+ bias) is per ray: dvec.
+  f32x16 acd[1][2];
+  {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      int ms = m0 + st * 32 + j;
+      ms = ms < a.M ? ms : a.M - 1;
+      const float* dv = a.dvec + (size_t)(ms / a.N) * HALF + wv * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(dv + 8 * g);
+        acd[0][st][4 * g + 0] = b.x;
+        acd[0][st][4 * g + 1] = b.y;
+        acd[0][st][4 * g + 2] = b.z;
+        acd[0][st][4 * g + 3] = b.w;
+      }
+    }
+  }
+  mfma_layer<32, 1>(a.wp + seg_off4(SEG_DIR), wv, act, 0, lane, acd);
+  __syncthreads();
+  acc_store<1, true>(act, wv * 32, lane, acd);
+  __syncthreads();
+  if (SAVE) save_rows(act, a.save + 9 * MS, m0, a.M, 32, WIDTH, tid);
+
+  // ---- colour head (VALU): rgb = sigmoid(W_c c + b)   (nerf.py:99, 119)
+  {
+    const float* wc = a.w.p[W_COLOR] + wv * 32;
+    const float* cr = act + sm * LDA + wv * 32;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+      const float4 cv = *reinterpret_cast<const float4*>(cr + k);
+      s0 = __builtin_fmaf(cv.x, wc[k], s0);
+      s1 = __builtin_fmaf(cv.x, wc[HALF + k], s1);
+      s2 = __builtin_fmaf(cv.x, wc[2 * HALF + k], s2);
+      s0 = __builtin_fmaf(cv.y, wc[k + 1], s0);
+      s1 = __builtin_fmaf(cv.y, wc[HALF + k + 1], s1);
+      s2 = __builtin_fmaf(cv.y, wc[2 * HALF + k + 1], s2);
+      s0 = __builtin_fmaf(cv.z, wc[k + 2], s0);
+      s1 = __builtin_fmaf(cv.z, wc[HALF + k + 2], s1);
+      s2 = __builtin_fmaf(cv.z, wc[2 * HALF + k + 2], s2);
+      s0 = __builtin_fmaf(cv.w, wc[k + 3], s0);
+      s1 = __builtin_fmaf(cv.w, wc[HALF + k + 3], s1);
+      s2 = __builtin_fmaf(cv.w, wc[2 * HALF + k + 3], s2);
+    }
+    scr[(wv * 64 + sm) * 3 + 0] = s0;
+    scr[(wv * 64 + sm) * 3 + 1] = s1;
+    scr[(wv * 64 + sm) * 3 + 2] = s2;
+  }
+  __syncthreads();
+  if (tid < 192) {
+    const int s = tid / 3, ch = tid - 3 * s;
+    if (m0 + s < a.M) {
+      const float z = ((scr[s * 3 + ch] + scr[(64 + s) * 3 + ch]) + (scr[(128 + s) * 3 + ch] + scr[(192 + s) * 3 + ch])) + a.w.p[B_COLOR][ch];
+      a.rgb[(size_t)(m0 + s) * 3 + ch] = 1.0f / (1.0f + expf(-z));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (called from api.cpp)
+// ------------------------------------------------------------------------------------------
+hipError_t launch_pack_weights(const Weights24& w, float4* out, int nseg, hipStream_t st) {
+  const int total = seg_off4(nseg);
+  hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, st, w, out, nseg);
+  return hipGetLastError();
+}
+
+hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st) {
+  const int tiles = (a.M + TM - 1) / TM;
+  const size_t lds = FIELD_LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (save)
+    hipLaunchKernelGGL(k_field_fwd<true>, dim3(tiles), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL(k_field_fwd<false>, dim3(tiles), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace nerf

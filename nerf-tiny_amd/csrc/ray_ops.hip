@@ -1,0 +1,345 @@
+// ray_ops.hip -- the per-ray (HBM/latency-bound) stages of the hot path for MI355X (gfx950):
+//   k_rays              pixel -> camera/world direction, coarse depths, per-ray direction-branch vector
+//   k_coarse            sigma -> weights (inclusive transmittance), C_coarse, inverse-CDF resampling
+//   k_merge             merge coarse+fine, five independent channel sorts, composite -> C_fine
+//   k_ray_loss          sum-of-squares loss and its gradient
+// One 64-lane wave owns one ray: the transmittance cumsum / CDF are wave scans (fp64 accumulator like
+// ATen's CPU cumsum, rounded to fp32 per element), searchsorted is a per-lane binary search in LDS and
+// the channel sorts are bitonic networks in LDS.  Built with -ffp-contract=off: the arithmetic order is
+// the reference's (SURVEY.md 8a SPEC); fused multiply-adds appear only where written as fmaf.
+#include "kernels.h"
+
+namespace nerf {
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rays: nerf.py:52-67 (pose split), 186-197 (pixel -> unit camera dir), 211 (world dir), 288 (coarse
+// depths, numpy.linspace in fp32) and the gamma_d half of dir_info (nerf.py:118) which is constant per ray.
+// grid = B blocks of 128 threads.
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(128) void k_rays(const RaysArgs a) {
+  __shared__ float gd[DIR_DIM];
+  const int ray = blockIdx.x, tid = threadIdx.x;
+  const float* pb = a.pb + (size_t)ray * 17;
+  // x <- row, y <- column (quirk Q2)
+  const float x = (float)a.row[ray], y = (float)a.col[ray];
+  float p[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) p[j] = (x * a.K[j] + y * a.K[3 + j]) + a.K[6 + j];
+  // F.normalize (nerf.py:193): ATen's CPU 2-norm accumulates acc = fma(v, v, acc) in fp32 and takes the
+  // square root in double; clamp_min(1e-12); true division.
+  const float ss = __builtin_fmaf(p[2], p[2], __builtin_fmaf(p[1], p[1], p[0] * p[0]));
+  float nrm = (float)sqrt((double)ss);
+  nrm = fmaxf(nrm, 1e-12f);
+  float d[3], dw[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) d[j] = p[j] / nrm;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dw[c] = (pb[5 * c] * d[0] + pb[5 * c + 1] * d[1]) + pb[5 * c + 2] * d[2];
+  const float near = pb[15], far = pb[16];
+  const float step = (far - near) / (float)(a.Nc - 1);
+  if (tid == 0) {
+    if (a.rayf) {
+      float* rf = a.rayf + (size_t)ray * RAYF;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rf[RF_R + 3 * c + k] = pb[5 * c + k];
+        rf[RF_O + c] = pb[5 * c + 3];
+        rf[RF_DCAM + c] = d[c];
+        rf[RF_DWRD + c] = dw[c];
+      }
+      rf[RF_NEAR] = near;
+      rf[RF_FAR] = far;
+      rf[RF_STEP] = step;
+      rf[RF_DELTA] = (far - near) / (float)a.Nc;  // quirk Q5 (nerf.py:293)
+      rf[22] = 0.f;
+      rf[23] = 0.f;
+    }
+    if (a.d_cam)
+      for (int c = 0; c < 3; ++c) a.d_cam[(size_t)ray * 3 + c] = d[c];
+    if (a.d_wrd)
+      for (int c = 0; c < 3; ++c) a.d_wrd[(size_t)ray * 3 + c] = dw[c];
+  }
+  if (a.t_c) {
+    for (int i = tid; i < a.Nc; i += 128) a.t_c[(size_t)ray * a.Nc + i] = (i == a.Nc - 1) ? far : ((float)i * step + near);
+  }
+  if (a.dvec) {
+    if (tid < 12) {
+      const int c = tid >> 2, l = tid & 3;
+      const float ph = dw[c] * __uint_as_float(kFreqDirBits[l]);
+      gd[c * 8 + 2 * l] = sinf(ph);
+      gd[c * 8 + 2 * l + 1] = cosf(ph);
+    }
+    __syncthreads();
+    const float* wr = a.w_dir + (size_t)tid * (WIDTH + DIR_DIM);
+    float s = a.b_dir[tid];
+#pragma unroll
+    for (int k = 0; k < DIR_DIM; ++k) s = __builtin_fmaf(wr[k], gd[k], s);
+    a.dvec[(size_t)ray * HALF + tid] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_coarse: get_density (nerf.py:263-272) with delta = (far-near)/Nc, color_cum (nerf.py:274-281, :320),
+// resample (nerf.py:225-261).  One wave per ray, 4 rays per 256-thread block.
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXN = 1024;
+
+
+__global__ __launch_bounds__(256) void k_coarse(const CoarseArgs a) {
+  __shared__ float s_w[4][MAXN];
+  __shared__ float s_cdf[4][MAXN];
+  __shared__ float s_t[4][MAXN];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray_raw = blockIdx.x * 4 + wv;
+  const bool live = ray_raw < a.B;
+  const int ray = live ? ray_raw : a.B - 1;
+  float near, far;
+  if (a.rayf) {
+    near = a.rayf[(size_t)ray * RAYF + RF_NEAR];
+    far = a.rayf[(size_t)ray * RAYF + RF_FAR];
+  } else {
+    near = a.near_far[2 * ray];
+    far = a.near_far[2 * ray + 1];
+  }
+  const float delta_c = (far - near) / (float)a.Nc;
+  // spacing of RAY 0 used for every ray (quirk Q6, nerf.py:233): t[0][1] - t[0][0]
+  float delta0 = a.delta0;
+  if (a.delta0_mode == 0) {
+    const float n0 = a.ray0_override ? a.near0 : a.rayf[RF_NEAR];
+    const float f0 = a.ray0_override ? a.far0 : a.rayf[RF_FAR];
+    const float st0 = (f0 - n0) / (float)(a.Nc - 1);
+    const float t1 = (a.Nc == 2) ? f0 : (1.0f * st0 + n0);
+    delta0 = t1 - n0;
+  }
+  float* w = s_w[wv];
+  float* cdf = s_cdf[wv];
+  float* tc = s_t[wv];
+
+  double carry = 0.0, carry2 = 0.0;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int base = 0; base < a.Nc; base += 64) {
+    const int i = base + lane;
+    const bool v = i < a.Nc;
+    const size_t gi = (size_t)ray * a.Nc + (v ? i : 0);
+    const float sg = v ? a.sigma[gi] : 0.f;
+    const float s = delta_c * sg;
+    double cs = wave_incl_scan((double)s, lane) + carry;
+    carry = __shfl(cs, 63);
+    const float T = expf(-(float)cs);
+    const float wi = v ? T * (1.0f - expf(-s)) : 0.f;
+    double cw = wave_incl_scan((double)wi, lane) + carry2;
+    carry2 = __shfl(cw, 63);
+    const float cd = (float)cw;
+    if (v) {
+      w[i] = wi;
+      cdf[i] = cd;
+      tc[i] = a.t_c[gi];
+      if (live && a.w_c) a.w_c[gi] = wi;
+      c0 += wi * a.rgb[gi * 3 + 0];
+      c1 += wi * a.rgb[gi * 3 + 1];
+      c2 += wi * a.rgb[gi * 3 + 2];
+      lo = fminf(lo, cd);
+      hi = fmaxf(hi, cd);
+    }
+  }
+  c0 = wave_sum(c0);
+  c1 = wave_sum(c1);
+  c2 = wave_sum(c2);
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if (live && lane == 0 && a.C_coarse) {
+    a.C_coarse[(size_t)ray * 3 + 0] = c0;
+    a.C_coarse[(size_t)ray * 3 + 1] = c1;
+    a.C_coarse[(size_t)ray * 3 + 2] = c2;
+  }
+  __syncthreads();
+  // u_j = lo + j * ((hi - lo)/(Nf+1)), j = 1..Nf  (numpy.linspace(lo, hi, Nf+2)[1:-1] in fp32, nerf.py:243-246)
+  const float step = (hi - lo) / (float)(a.Nf + 1);
+  bool bad = false;
+  for (int j = lane; j < a.Nf; j += 64) {
+    const float u = (float)(j + 1) * step + lo;
+    // searchsorted(cdf, u) (left) = number of cdf entries < u
+    int lo_i = 0, hi_i = a.Nc;
+    while (lo_i < hi_i) {
+      const int mid = (lo_i + hi_i) >> 1;
+      if (cdf[mid] < u) lo_i = mid + 1; else hi_i = mid;
+    }
+    int k = lo_i - 1;
+    if (k > a.Nf - 1 || k < 0) bad = true;  // the condition of nerf.py:251 (quirk Q7)
+    k = k < 0 ? 0 : (k > a.Nc - 1 ? a.Nc - 1 : k);
+    const float slope = (k + 1 < a.Nc) ? delta0 / (w[k + 1] + 1e-7f) : 0.f;
+    const float tf = tc[k] + (u - cdf[k]) * slope;
+    if (live) a.t_f[(size_t)ray * a.Nf + j] = tf;
+  }
+  if (live && bad && a.status) atomicOr(a.status, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_merge: nerf.py:302-321.  cat -> sort(dim=1) of a [B,N,5] bundle = five INDEPENDENT ascending channel
+// sorts (quirk Q1), delta_i = t_{i+1} - t_i with the last = `last`, weights, C_fine.
+// One wave (64-thread block) per ray; bitonic sort over P = next_pow2(N) slots per channel in LDS.
+// Ties are broken by original index (a stable sort); indices are kept for the backward pass.
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int P = a.P, N = a.Nc + a.Nf;
+  float* val = reinterpret_cast<float*>(smem_raw);                  // [5][P]
+  uint16_t* idx = reinterpret_cast<uint16_t*>(val + 5 * (size_t)P);  // [5][P]
+  const int lane = threadIdx.x;
+  const int ray = blockIdx.x;
+  // load: channel 0 = t, 1..3 = rgb, 4 = sigma
+  for (int i = lane; i < P; i += 64) {
+    float v[5];
+    if (i < a.Nc) {
+      const size_t g = (size_t)ray * a.Nc + i;
+      v[0] = a.t_c[g]; v[1] = a.rgb_c[g * 3]; v[2] = a.rgb_c[g * 3 + 1]; v[3] = a.rgb_c[g * 3 + 2]; v[4] = a.sig_c[g];
+    } else if (i < N) {
+      const size_t g = (size_t)ray * a.Nf + (i - a.Nc);
+      v[0] = a.t_f[g]; v[1] = a.rgb_f[g * 3]; v[2] = a.rgb_f[g * 3 + 1]; v[3] = a.rgb_f[g * 3 + 2]; v[4] = a.sig_f[g];
+    } else {
+      v[0] = v[1] = v[2] = v[3] = v[4] = INFINITY;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      val[c * P + i] = v[c];
+      idx[c * P + i] = (uint16_t)i;
+    }
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int tI = lane; tI < (P >> 1); tI += 64) {
+        const int i = ((tI & ~(j - 1)) << 1) | (tI & (j - 1));  // element with bit j clear
+        const int l = i | j;
+        const bool asc = (i & k) == 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const float x = val[c * P + i], y = val[c * P + l];
+          const uint16_t xi = idx[c * P + i], yi = idx[c * P + l];
+          const bool gt = (x > y) || (x == y && xi > yi);
+          if (gt == asc) {
+            val[c * P + i] = y; val[c * P + l] = x;
+            idx[c * P + i] = yi; idx[c * P + l] = xi;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // composite over the sorted channels
+  double carry = 0.0;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int base = 0; base < N; base += 64) {
+    const int i = base + lane;
+    const bool v = i < N;
+    const float ti = v ? val[i] : 0.f;
+    const float dl = (v && i + 1 < N) ? (val[i + 1] - ti) : a.last;
+    const float sg = v ? val[4 * P + i] : 0.f;
+    const float s = v ? dl * sg : 0.f;
+    double cs = wave_incl_scan((double)s, lane) + carry;
+    carry = __shfl(cs, 63);
+    const float T = expf(-(float)cs);
+    const float wi = v ? T * (1.0f - expf(-s)) : 0.f;
+    if (v) {
+      const float r = val[P + i], g = val[2 * P + i], b = val[3 * P + i];
+      c0 += wi * r; c1 += wi * g; c2 += wi * b;
+      const size_t gi = (size_t)ray * N + i;
+      if (a.w) a.w[gi] = wi;
+      if (a.bundle) {
+        float* o = a.bundle + gi * 5;
+        o[0] = ti; o[1] = r; o[2] = g; o[3] = b; o[4] = sg;
+      }
+      if (a.perm) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) a.perm[((size_t)ray * 5 + c) * N + i] = idx[c * P + i];
+      }
+    }
+  }
+  c0 = wave_sum(c0);
+  c1 = wave_sum(c1);
+  c2 = wave_sum(c2);
+  if (lane == 0) {
+    a.C_fine[(size_t)ray * 3 + 0] = c0;
+    a.C_fine[(size_t)ray * 3 + 1] = c1;
+    a.C_fine[(size_t)ray * 3 + 2] = c2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ray_loss: nerf.py:325-331 (sum, not mean) and d loss / dC.  Single 1024-thread block (B*3 elements).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ray_loss(const float* Cc, const float* Cf, const float* Ct, int n, float* loss, float* dCc,
+                                                   float* dCf) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float e1 = Cc[i] - Ct[i], e2 = Cf[i] - Ct[i];
+    acc += e1 * e1 + e2 * e2;
+    if (dCc) dCc[i] = 2.0f * e1;
+    if (dCf) dCf[i] = 2.0f * e2;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    loss[0] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_rays(const RaysArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_rays, dim3(a.B), dim3(128), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_coarse, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+size_t merge_lds_bytes(int P) { return (size_t)5 * P * (sizeof(float) + sizeof(uint16_t)); }
+hipError_t launch_merge(const MergeArgs& a, hipStream_t st) {
+  const size_t lds = merge_lds_bytes(a.P);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_merge, dim3(a.B), dim3(64), lds, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_ray_loss(const float* Cc, const float* Cf, const float* Ct, int B, float* loss, float* dCc, float* dCf, hipStream_t st) {
+  hipLaunchKernelGGL(k_ray_loss, dim3(1), dim3(1024), 0, st, Cc, Cf, Ct, B * 3, loss, dCc, dCf);
+  return hipGetLastError();
+}
+
+}  // namespace nerf

@@ -1,0 +1,202 @@
+"""Host-side mirror of the reference's ``nerf`` module surface for the volume-rendering hot path.
+
+Same names, constructor arguments, call signatures and ``state_dict`` keys as the reference
+(``/root/reference/nerf.py``): ``NeRFModel(num_coarse, num_fine, batch_ray)`` (nerf.py:170),
+``model(row, column, poses_bound, K_inv) -> (C_coarse, C_fine)`` (nerf.py:333-348),
+``model.ray_loss`` (nerf.py:325-331), ``model.network.parameters()`` for Adam (nerf.py:425).
+The arithmetic happens in libnerf_hip.so (hand-written gfx950 kernels) through a
+``torch.autograd.Function``; PyTorch only owns device memory, the stream and autograd plumbing.
+There is NO fallback: calling a model that does not live on a ROCm device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+
+# module-global device like the reference (nerf.py:40, :387); the model follows its parameters' device.
+device = None
+
+LAST_DELTA = 0.0001  # nerf.py:286
+
+
+class Activation(nn.Module):
+    """nerf.py:69-74 (abs); kept so pickled/introspected module trees look the same."""
+
+    def forward(self, x):
+        return torch.abs(x)
+
+
+class Network(nn.Module):
+    """Parameter container with the reference's module tree (nerf.py:76-99) so that ``state_dict``
+    keys, shapes and ``parameters()`` order are identical.  The forward pass is the fused HIP kernel
+    (csrc/field_fwd.hip); this module cannot be called on its own."""
+
+    def __init__(self, point_dim=60, dir_dim=24, depth=8, width=256, batch_size=8, layers_skip=[4]):
+        super().__init__()
+        if (point_dim, dir_dim, depth, width, list(layers_skip)) != (60, 24, 8, 256, [4]):
+            raise ValueError("libnerf_hip.so is built for the reference's architecture: 60/24 inputs, 8x256, skip at 4")
+        self.depth, self.width, self.batch_size, self.layers_skip = depth, width, batch_size, layers_skip
+        self.point_layer = nn.ModuleList([nn.Sequential(nn.Linear(point_dim, width), nn.ReLU(True))])
+        for i in range(1, depth):
+            fan_in = width + point_dim if i in layers_skip else width
+            self.point_layer.append(nn.Sequential(nn.Linear(fan_in, width), nn.ReLU(True)))
+        self.sigma_layer = nn.Sequential(nn.Linear(width, 1), Activation())
+        self.point_info = nn.Linear(width, width)
+        self.dir_info = nn.Sequential(nn.Linear(width + dir_dim, width // 2), nn.ReLU(True))
+        self.color_layer = nn.Sequential(nn.Linear(width // 2, 3), nn.Sigmoid())
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("Network is evaluated inside libnerf_hip.so (NeRFModel.forward); it has no eager path")
+
+
+class Encoder(nn.Module):
+    """nerf.py:126-167: no parameters; the encoding is fused into the field kernel."""
+
+    def __init__(self, L_point=10, L_dir=4, batch_size=8):
+        super().__init__()
+        if (L_point, L_dir) != (10, 4):
+            raise ValueError("libnerf_hip.so is built for L_point=10, L_dir=4")
+        self.L_point, self.L_dir, self.batch_size = L_point, L_dir, batch_size
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("Encoder is fused into libnerf_hip.so (NeRFModel.forward); it has no eager path")
+
+
+class ResampleIndexError(RuntimeError):
+    """Raised (when ``model.check_resample`` is on) where the reference prints a banner and exit(0)s (nerf.py:251-253)."""
+
+
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, row, col, pb, K9, ray0, *params):
+        B = row.shape[0]
+        Nc, Nf = model.num_coarse, model.num_fine
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        flags = _abi.SAVE_FOR_BACKWARD if need_grad else 0
+        ws = model._workspace(B, flags)
+        dev = row.device
+        C_c = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        C_f = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        wptr = _abi.ptr_array(params)
+        _abi.check(_abi.lib().nerf_hip_forward(wptr, row.data_ptr(), col.data_ptr(), pb.data_ptr(), K9,
+                                               ray0, B, Nc, Nf, LAST_DELTA, C_c.data_ptr(), C_f.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), flags, stream))
+        if need_grad:
+            model._ws_generation += 1
+            ctx.generation = model._ws_generation
+            ctx.model, ctx.ws, ctx.flags, ctx.B = model, ws, flags, B
+            ctx.params = params
+        return C_c, C_f
+
+    @staticmethod
+    def backward(ctx, dC_c, dC_f):
+        model = ctx.model
+        if ctx.generation != model._ws_generation:
+            raise RuntimeError("the workspace of this forward was reused by a later forward; call backward first")
+        params = ctx.params
+        grads = [torch.empty_like(p) for p in params]
+        dC_c = dC_c.contiguous().float()
+        dC_f = dC_f.contiguous().float()
+        stream = torch.cuda.current_stream(dC_c.device).cuda_stream
+        _abi.check(_abi.lib().nerf_hip_backward(_abi.ptr_array(params), dC_c.data_ptr(), dC_f.data_ptr(), ctx.B,
+                                                model.num_coarse, model.num_fine, LAST_DELTA, _abi.ptr_array(grads),
+                                                ctx.ws.data_ptr(), ctx.ws.numel(), ctx.flags, stream))
+        return (None, None, None, None, None, None, *grads)
+
+
+class NeRFModel(nn.Module):
+    """Drop-in for the reference's ``NeRFModel`` (nerf.py:169-348)."""
+
+    def __init__(self, num_coarse=64, num_fine=128, batch_ray=8):
+        super().__init__()
+        self.encoder = Encoder(batch_size=batch_ray)
+        self.network = Network(batch_size=batch_ray)
+        self.num_coarse = num_coarse
+        self.num_fine = num_fine
+        self.batch_ray = batch_ray
+        #: mimic nerf.py:251-253 (costs one host sync per call, like the reference): raise instead of exit(0)
+        self.check_resample = False
+        #: (near, far) of the GLOBAL ray 0 when one batch is sharded over several GPUs (quirk Q6); None = local ray 0
+        self.ray0_near_far = None
+        self._ws = {}
+        self._ws_generation = 0
+
+    # ----- plumbing -------------------------------------------------------------------------
+    def _workspace(self, B, flags):
+        dev = self.network.point_info.weight.device
+        key = (B, self.num_coarse, self.num_fine, flags, dev)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = _abi.ws_bytes(B, self.num_coarse, self.num_fine, flags)
+            ws = torch.empty(n, dtype=torch.uint8, device=dev)
+            assert ws.data_ptr() % 256 == 0
+            self._ws = {key: ws}  # keep one workspace alive
+        return ws
+
+    def __getstate__(self):  # torch.save(model) (nerf.py:491) must not pickle the workspace
+        d = dict(self.__dict__)
+        d["_ws"] = {}
+        return d
+
+    def _params(self):
+        ps = list(self.network.parameters())
+        for p in ps:
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise RuntimeError("network parameters must be contiguous fp32")
+        return ps
+
+    # ----- reference surface ----------------------------------------------------------------
+    def ray_loss(self, C_coarse, C_fine, C_true):
+        """nerf.py:325-331: sum (not mean) of squared errors of both colours."""
+        return _RayLossFn.apply(C_coarse, C_fine, C_true)
+
+    def forward(self, row, column, poses_bound, K_inv):
+        """nerf.py:333-348.  row/column [B] i64, poses_bound [B,17] (any float dtype), K_inv [3,3];
+        CPU or device tensors.  Returns (C_coarse, C_fine) [B,3] fp32 on the model's device."""
+        ps = self._params()
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("NeRFModel runs only on a ROCm device (MI355X): model.to('cuda'); there is no CPU path")
+        if row.shape[0] != self.batch_ray:
+            raise ValueError(f"batch of {row.shape[0]} rays, model built for batch_ray={self.batch_ray} (nerf.py:172-176)")
+        K9 = _abi.f32_array(K_inv.detach().to("cpu", torch.float32).reshape(-1).tolist())
+        pb = poses_bound.to(torch.float).to(dev).contiguous()  # cast first like nerf.py:338
+        row_d = row.to(dev, torch.int64).contiguous()
+        col_d = column.to(dev, torch.int64).contiguous()
+        ray0 = _abi.f32_array(self.ray0_near_far) if self.ray0_near_far is not None else None
+        C_c, C_f = _RenderFn.apply(self, row_d, col_d, pb, K9, ray0, *ps)
+        if self.check_resample:
+            st = C.c_uint32(0)
+            ws = next(iter(self._ws.values()))
+            _abi.check(_abi.lib().nerf_hip_read_status(ws.data_ptr(), ws.numel(), C.byref(st),
+                                                       torch.cuda.current_stream(dev).cuda_stream))
+            if st.value & _abi.STATUS_RESAMPLE_INDEX:
+                raise ResampleIndexError("resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253)")
+        return C_c, C_f
+
+
+class _RayLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, C_c, C_f, C_t):
+        C_c, C_f, C_t = C_c.contiguous(), C_f.contiguous(), C_t.contiguous().to(C_c.device, torch.float32)
+        B = C_c.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=C_c.device)
+        need = torch.is_grad_enabled() and (C_c.requires_grad or C_f.requires_grad)
+        dCc = torch.empty_like(C_c) if need else None
+        dCf = torch.empty_like(C_f) if need else None
+        _abi.check(_abi.lib().nerf_hip_ray_loss(C_c.data_ptr(), C_f.data_ptr(), C_t.data_ptr(), B, loss.data_ptr(),
+                                                dCc.data_ptr() if need else None, dCf.data_ptr() if need else None,
+                                                torch.cuda.current_stream(C_c.device).cuda_stream))
+        if need:
+            ctx.save_for_backward(dCc, dCf)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dCc, dCf = ctx.saved_tensors
+        return g * dCc, g * dCf, None

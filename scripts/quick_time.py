@@ -1,0 +1,22 @@
+"""Quick forward timing on the GPU box (development aid; bench.py is the contract)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch
+import nerf_oracle as O
+import nerf_tiny_amd as P
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda:0")
+row, col, pb, K, Ct = O.lego_inputs(B, seed=0)
+m = P.NeRFModel(64, 128, B); m.load_state_dict(O.make_weights(0)); m = m.to(dev)
+row, col, pb = row.to(dev), col.to(dev), pb.float().to(dev)
+with torch.no_grad():
+    for _ in range(3): m(row, col, pb, K)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n): m(row, col, pb, K)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+print(f"B={B}: {dt*1e3:.3f} ms/batch  {B/dt:,.0f} rays/s  ({B/dt*227131392/1e12:.1f} TFLOP/s of 157.3)")

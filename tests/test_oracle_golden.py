@@ -1,0 +1,72 @@
+"""CPU: the oracle restatement against the golden vectors captured from the imported reference
+(tests/golden/make_golden.py).  Forward outputs and stage intermediates must be BIT-identical;
+gradients (multi-threaded accumulation order) within 1e-5 L2-rel."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_inputs, l2_rel, load_golden
+
+CASES = ["cfg1_lego_crop32", "cfg1_lego_crop32_sharp", "cfg4_fern_rand512", "small_16_32"]
+
+
+@pytest.mark.parametrize("name", CASES + ["cfg2_lego_rand4096"])
+def test_forward_bit_identical(oracle, name):
+    g = load_golden(name)
+    row, col, pb, K, _ = golden_inputs(g)
+    params = oracle.make_weights(int(g["seed"]), bool(g["sharp"]))
+    st = {}
+    with torch.no_grad():
+        Cc, Cf = oracle.render(params, row, col, pb, K, int(g["Nc"]), int(g["Nf"]), stages=st)
+    assert np.array_equal(Cc.numpy(), g["C_coarse"])
+    assert np.array_equal(Cf.numpy(), g["C_fine"])
+    n = g["st_t_c"].shape[0]
+    for k in ("t_c", "pts_c", "d_wrd", "gd", "sig_c", "rgb_c", "w_c", "t_f", "pts_f", "sig_f", "rgb_f"):
+        assert np.array_equal(st[k][:n].numpy(), g["st_" + k]), k
+    gp = oracle.encode(st["pts_c"][:n], oracle.frequencies()[0])
+    assert np.array_equal(gp.numpy(), g["st_gp_c"])
+
+
+@pytest.mark.parametrize("name", ["cfg1_lego_crop32", "small_16_32"])
+def test_gradients(oracle, name):
+    g = load_golden(name)
+    row, col, pb, K, Ct = golden_inputs(g)
+    params = oracle.make_weights(int(g["seed"]), bool(g["sharp"]))
+    _, _, loss, grads = oracle.loss_and_grads(params, row, col, pb, K, Ct, int(g["Nc"]), int(g["Nf"]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    for k, v in grads.items():
+        assert abs(float(v.double().norm()) - float(g["gnorm_" + k])) <= 1e-5 * float(g["gnorm_" + k]), k
+        if "grad_" + k in g:
+            assert l2_rel(v, g["grad_" + k]) < 1e-5, k
+        else:
+            assert l2_rel(v.flatten()[::97], g["gslice_" + k]) < 1e-5, k
+
+
+def test_frequencies_bits(oracle):
+    """quirk Q3: non-integer octaves; bit patterns baked into csrc/common.h."""
+    fp, fd = oracle.frequencies()
+    want_p = "40490fdb 40d928ae 416a8b6c 41fd527b 4288cd33 4313c0fa 439f953c 442c5bef 44ba2881 45490fdb".split()
+    want_d = "40490fdb 40fd527a 419f953c 42490fdb".split()
+    assert [f"{x:08x}" for x in fp.numpy().view(np.uint32)] == want_p
+    assert [f"{x:08x}" for x in fd.numpy().view(np.uint32)] == want_d
+
+
+def test_resample_guard_fires_on_zero_density(oracle):
+    """quirk Q7: all-equal coarse weights -> index condition of nerf.py:251 (the reference exit(0)s)."""
+    row, col, pb, K, _ = oracle.lego_inputs(8, seed=0)
+    params = oracle.make_weights(0)
+    params["network.sigma_layer.0.weight"].zero_()
+    params["network.sigma_layer.0.bias"].zero_()
+    with pytest.raises(oracle.ResampleIndexError):
+        with torch.no_grad():
+            oracle.render(params, row, col, pb, K, 64, 128)
+
+
+def test_param_table_matches_package(oracle, pkg):
+    m = pkg.NeRFModel(64, 128, 8)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(oracle.PARAM_SHAPES.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(oracle.PARAM_SHAPES[k]), k
+    assert sum(v.numel() for v in sd.values()) == 593924
+    assert [tuple(p.shape) for p in m.network.parameters()] == [tuple(s) for s in oracle.PARAM_SHAPES.values()]
