@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the MI355X volume-rendering hot path on BASELINE.json's cfg2 workload.
+
+A "step" = one full forward of the hot path (ray generation, 64 coarse + 128 fine samples per ray,
+encode, 8x256 MLP per sample, resample, merge/sort, composite) over one batch of 4096 synthetic rays of
+a 400x400 lego-like view, fp32, inputs already resident in HBM.  `--mode train` times forward + ray_loss +
+backward instead (no optimizer), reported as an extra metric.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1: launched under torch.distributed.run,
+one rank per GPU; every rank renders its own 4096-ray batches -- image-space ray batches are independent
+units, so there is no data-path collective: scaling = "weak").  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 1_182_976  # GEMM MACs x 2 of one MLP evaluation
+B, NC, NF = 4096, 64, 128
+FLOP_PER_RAY_FWD = FLOP_PER_SAMPLE * (NC + NF)  # 227,131,392
+FLOP_PER_RAY_TRAIN = 676_282_368
+PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md chip table (fp32 matrix, dense)
+
+
+def synth_inputs(seed):
+    """cfg2: row, col ~ U{0..399}, one lego-like pose, near/far 2/6.  Pure numpy/torch; the
+    same generator as oracle.lego_inputs, restated here so the product path never imports the oracle."""
+    import numpy as np
+    import torch
+
+    H = W = 400
+    angle = 0.6911112070083618
+    focal = 0.5 * W / np.tan(0.5 * angle)
+    pose = np.array([[-0.99990219, 0.00419225, -0.01334572, -0.05379832],
+                     [-0.01398868, -0.29965907, 0.95394367, 3.84547043],
+                     [-4.66e-10, 0.95403719, 0.29968831, 1.20808232]], dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    row = rng.integers(0, W, size=B)
+    col = rng.integers(0, H, size=B)
+    m = np.concatenate((pose, np.array([[H], [W], [focal]], dtype=np.float64)), axis=1).flatten()
+    pb = np.tile(np.concatenate((m, [2.0, 6.0])), (B, 1))
+    K_inv = torch.tensor([[1.0, 0.0, -0.5 * W], [0.0, -1.0, 0.5 * H], [0.0, 0.0, -focal]]).float().t()
+    C_true = np.random.default_rng(seed + 1).uniform(0, 1, size=(B, 3)).astype(np.float32)
+    return (torch.from_numpy(row.astype(np.int64)), torch.from_numpy(col.astype(np.int64)), torch.from_numpy(pb), K_inv,
+            torch.from_numpy(C_true))
+
+
+def synth_weights(seed):
+    """random-init weights of the reference architecture: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) per tensor."""
+    import math
+
+    import numpy as np
+    import torch
+
+    import nerf_tiny_amd as P
+
+    m = P.NeRFModel(NC, NF, B)
+    sd = m.state_dict()
+    for i, (k, v) in enumerate(sd.items()):
+        fan_in = v.shape[1] if v.dim() == 2 else sd[k.replace("bias", "weight")].shape[1]
+        bound = 1.0 / math.sqrt(fan_in)
+        sd[k] = torch.from_numpy(np.random.default_rng([seed, i]).uniform(-bound, bound, size=tuple(v.shape)).astype(np.float32))
+    m.load_state_dict(sd)
+    return m
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (bit-identical restatement of the reference, 'port') timed on this box's host cores on the SAME
+    cfg2 workload: one warm-up + as many full 4096-ray forwards as fit the budget (>= 1), best time."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerf_oracle as O
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    row, col, pb, K, _ = O.lego_inputs(B, seed=0)
+    params = O.make_weights(0)
+    with torch.no_grad():
+        O.render(params, row[:256], col[:256], pb[:256], K, NC, NF)  # warm-up (small)
+        best, n, t_start = None, 0, time.perf_counter()
+        while n < 1 or (time.perf_counter() - t_start) < seconds_budget and n < 5:
+            t0 = time.perf_counter()
+            O.render(params, row, col, pb, K, NC, NF)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            n += 1
+    return {"value": round(B / best, 1), "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full forward(s) of the same 4096-ray x (64+128) batch, torch CPU fp32, best of {n}; "
+                      f"{best:.2f} s/batch"}
+
+
+def read_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary, if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("field_fwd_fine", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import nerf_tiny_amd as P
+    from nerf_tiny_amd import _abi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    _abi.lib()  # fail loudly if the HIP library is missing
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    row, col, pb, K, C_true = synth_inputs(seed=1000 + rank)
+    model = synth_weights(seed=0).to(dev)
+    row, col, pb, C_true = row.to(dev), col.to(dev), pb.float().to(dev), C_true.to(dev)
+    train = args.mode == "train"
+
+    def step():
+        if train:
+            for p in model.network.parameters():
+                p.grad = None
+            Cc, Cf = model(row, col, pb, K)
+            loss = model.ray_loss(Cc, Cf, C_true)
+            loss.backward()
+        else:
+            with torch.no_grad():
+                model(row, col, pb, K)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    _abi.profile_begin(args.steps * 16 + 16)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = _abi.profile_end()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        rays = B * world * args.steps
+        value = rays / elapsed
+        # dominant kernel: the fine-pass launch of the fused field kernel (B*Nf samples per launch)
+        dom = "field_fwd_fine"
+        ms_sum, n_launch = prof.get(dom, (0.0, 0))
+        avg_ms = ms_sum / max(n_launch, 1)
+        flop_launch = FLOP_PER_SAMPLE * B * NF
+        achieved = flop_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        flop_ray = FLOP_PER_RAY_TRAIN if train else FLOP_PER_RAY_FWD
+        out = {
+            "metric": "rays/sec (64 coarse + 128 fine samples), lego 400x400" + (" [train step: fwd+loss+bwd]" if train else ""),
+            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: lego-like 400x400 view, 4096-ray batches, 64 coarse + 128 fine samples, fp32, "
+                                   "random-init 8x256 NeRF MLP (593,924 params)", "rays_per_step_per_gpu": B,
+                       "mode": args.mode, "parallelism": f"ray-batch x{world} (independent batches, no collective)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": read_traffic(),
+                         "kernel": "k_field_fwd (fine pass)", "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
+                         "flop_per_launch": flop_launch},
+            "whole_path_tflops": round(value / world * flop_ray / 1e12, 2),
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline()
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = round(value / cb["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

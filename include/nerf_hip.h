@@ -101,6 +101,21 @@ int nerf_hip_ray_loss(const float* C_coarse, const float* C_fine, const float* C
 /* Copies the status word of the last forward on this workspace to the host (synchronises `stream`). */
 int nerf_hip_read_status(const void* ws, size_t ws_bytes, uint32_t* status, void* stream);
 
+/*
+ * Optional per-kernel timing with HIP events recorded on the caller's stream around every kernel the
+ * library launches (used by bench.py for the roofline figure; off by default, not thread-safe).
+ * begin() creates 2*max_launches events; end() waits for them, adds each launch's elapsed ms to
+ * ms_sum[kernel id] / count[kernel id] (arrays of n_kernels) and destroys the events.
+ */
+enum {
+  NERF_HIP_K_PACK = 0, NERF_HIP_K_RAYS = 1, NERF_HIP_K_FIELD_COARSE = 2, NERF_HIP_K_COARSE = 3,
+  NERF_HIP_K_FIELD_FINE = 4, NERF_HIP_K_MERGE = 5,
+  NERF_HIP_K_BWD_MERGE = 6, NERF_HIP_K_BWD_FIELD_FINE = 7, NERF_HIP_K_BWD_COARSE = 8,
+  NERF_HIP_K_BWD_FIELD_COARSE = 9, NERF_HIP_K_BWD_DW = 10, NERF_HIP_K_COUNT = 11
+};
+int nerf_hip_profile_begin(int max_launches);
+int nerf_hip_profile_end(double* ms_sum, int* count, int n_kernels);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage entry points (same kernels as nerf_hip_forward; exposed so each row of the hot-path
  * table can be parity-checked on its own).

@@ -24,6 +24,8 @@ _PROTOS = {
     "nerf_hip_backward": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_size_t, C.c_int, _p]),
     "nerf_hip_ray_loss": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, _p]),
     "nerf_hip_read_status": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_uint32), _p]),
+    "nerf_hip_profile_begin": (C.c_int, [C.c_int]),
+    "nerf_hip_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     "nerf_hip_rays": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p]),
     "nerf_hip_field": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_size_t, _p]),
     "nerf_hip_coarse_composite": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
@@ -65,6 +67,23 @@ def ws_bytes(B: int, Nc: int, Nf: int, flags: int) -> int:
     n = C.c_size_t(0)
     check(lib().nerf_hip_ws_bytes(B, Nc, Nf, flags, C.byref(n)))
     return int(n.value)
+
+
+KERNEL_NAMES = ("pack_weights", "rays", "field_fwd_coarse", "coarse_composite", "field_fwd_fine", "merge_composite",
+                "bwd_merge", "bwd_field_fine", "bwd_coarse", "bwd_field_coarse", "bwd_dw")
+
+
+def profile_begin(max_launches: int) -> None:
+    check(lib().nerf_hip_profile_begin(max_launches))
+
+
+def profile_end() -> dict:
+    """-> {kernel name: (total ms, launches)}"""
+    n = len(KERNEL_NAMES)
+    ms = (C.c_double * n)()
+    cnt = (C.c_int * n)()
+    check(lib().nerf_hip_profile_end(ms, cnt, n))
+    return {KERNEL_NAMES[i]: (ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
 
 def ptr_array(tensors) -> "C.Array":

@@ -100,6 +100,29 @@ Weights24 as_w24(const float* const* w) {
   return r;
 }
 
+// ---- optional per-kernel HIP-event timing (bench.py's roofline leg); off by default ----
+struct Prof {
+  bool on = false;
+  int cap = 0, used = 0;
+  hipEvent_t* ev = nullptr;  // 2 per launch
+  int* kid = nullptr;
+} g_prof;
+
+struct ProfScope {
+  hipStream_t st;
+  int slot = -1;
+  ProfScope(int kernel_id, hipStream_t s) : st(s) {
+    if (g_prof.on && g_prof.used < g_prof.cap) {
+      slot = g_prof.used++;
+      g_prof.kid[slot] = kernel_id;
+      (void)hipEventRecord(g_prof.ev[2 * slot], st);
+    }
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  }
+};
+
 template <class T>
 T* at(void* ws, size_t off) {
   return reinterpret_cast<T*>(static_cast<unsigned char*>(ws) + off);
@@ -135,7 +158,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   const Weights24 w = as_w24(weights24);
 
   HIP_TRY(hipMemsetAsync(at<void>(ws, L.status), 0, 256, st));
-  HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
+  { ProfScope ps(NERF_HIP_K_PACK, st); HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st)); }
 
   RaysArgs ra;
   memset(&ra, 0, sizeof(ra));
@@ -146,7 +169,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ra.dvec = at<float>(ws, L.dvec);
   ra.w_dir = w.p[W_DIR]; ra.b_dir = w.p[B_DIR];
   ra.t_c = at<float>(ws, L.t_c);
-  HIP_TRY(launch_rays(ra, st));
+  { ProfScope ps(NERF_HIP_K_RAYS, st); HIP_TRY(launch_rays(ra, st)); }
 
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));
@@ -160,7 +183,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.sigma = at<float>(ws, L.sig_c);
   fa.N = Nc; fa.M = B * Nc;
   if (save) { fa.save = at<float>(ws, L.save_c); fa.spre = at<float>(ws, L.spre_c); }
-  HIP_TRY(launch_field_fwd(fa, save, st));
+  { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(launch_field_fwd(fa, save, st)); }
 
   CoarseArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -171,7 +194,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   if (ray0_near_far) { ca.ray0_override = 1; ca.near0 = ray0_near_far[0]; ca.far0 = ray0_near_far[1]; }
   ca.w_c = at<float>(ws, L.w_c); ca.C_coarse = C_coarse; ca.t_f = at<float>(ws, L.t_f);
   ca.status = at<uint32_t>(ws, L.status);
-  HIP_TRY(launch_coarse(ca, st));
+  { ProfScope ps(NERF_HIP_K_COARSE, st); HIP_TRY(launch_coarse(ca, st)); }
 
   // fine pass (nerf.py:299), same network (quirk Q10)
   fa.t = at<float>(ws, L.t_f);
@@ -179,7 +202,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.sigma = at<float>(ws, L.sig_f);
   fa.N = Nf; fa.M = B * Nf;
   if (save) { fa.save = at<float>(ws, L.save_f); fa.spre = at<float>(ws, L.spre_f); }
-  HIP_TRY(launch_field_fwd(fa, save, st));
+  { ProfScope ps(NERF_HIP_K_FIELD_FINE, st); HIP_TRY(launch_field_fwd(fa, save, st)); }
 
   MergeArgs ma;
   memset(&ma, 0, sizeof(ma));
@@ -190,8 +213,40 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ma.last = last_delta;
   if (save) { ma.bundle = at<float>(ws, L.bundle); ma.w = at<float>(ws, L.w_m); ma.perm = at<uint16_t>(ws, L.perm); }
   ma.C_fine = C_fine;
-  HIP_TRY(launch_merge(ma, st));
+  { ProfScope ps(NERF_HIP_K_MERGE, st); HIP_TRY(launch_merge(ma, st)); }
   return NERF_HIP_OK;
+}
+
+int nerf_hip_profile_begin(int max_launches) {
+  if (g_prof.ev) return fail(NERF_HIP_ERR_ARG, "profile already active");
+  if (max_launches < 1 || max_launches > (1 << 20)) return fail(NERF_HIP_ERR_ARG, "bad max_launches");
+  g_prof.ev = new hipEvent_t[2 * (size_t)max_launches];
+  g_prof.kid = new int[max_launches];
+  for (int i = 0; i < 2 * max_launches; ++i) HIP_TRY(hipEventCreate(&g_prof.ev[i]));
+  g_prof.cap = max_launches;
+  g_prof.used = 0;
+  g_prof.on = true;
+  return NERF_HIP_OK;
+}
+
+int nerf_hip_profile_end(double* ms_sum, int* count, int n_kernels) {
+  if (!g_prof.ev) return fail(NERF_HIP_ERR_ARG, "profile not active");
+  g_prof.on = false;
+  for (int k = 0; k < n_kernels; ++k) { if (ms_sum) ms_sum[k] = 0.0; if (count) count[k] = 0; }
+  int rc = NERF_HIP_OK;
+  for (int i = 0; i < g_prof.used; ++i) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    if (e != hipSuccess) { rc = fail(NERF_HIP_ERR_DEVICE, "profile event: %s", hipGetErrorString(e)); break; }
+    const int k = g_prof.kid[i];
+    if (k >= 0 && k < n_kernels) { if (ms_sum) ms_sum[k] += ms; if (count) count[k] += 1; }
+  }
+  for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+  delete[] g_prof.ev;
+  delete[] g_prof.kid;
+  g_prof.ev = nullptr; g_prof.kid = nullptr; g_prof.cap = g_prof.used = 0;
+  return rc;
 }
 
 int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, const float* dC_fine, int B, int Nc, int Nf,
