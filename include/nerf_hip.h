@@ -65,6 +65,11 @@ const char* nerf_hip_last_error(void);
 /* Bytes of device workspace nerf_hip_forward / nerf_hip_backward need for these sizes. */
 int nerf_hip_ws_bytes(int B, int Nc, int Nf, int flags, size_t* bytes);
 
+/* Byte offset of a named intermediate inside the workspace (introspection for tests / debugging):
+ * "t_c" "sig_c" "rgb_c" "w_c" "t_f" "sig_f" "rgb_f", and with NERF_HIP_SAVE_FOR_BACKWARD also "bundle" "w_m" "perm"
+ * "save" "G" "dz" "dspre" "drgb_c" "dsig_c" "drgb_f" "dsig_f" "dt_f" (gradient buffers are valid after backward). */
+int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_t* offset);
+
 /*
  * Whole forward: replaces NeRFModel.forward -> render_rays (nerf.py:333-348, 286-323).
  *   row, col        [B] i64   pixel coordinates; x <- row, y <- col (nerf.py:186-188)
@@ -86,12 +91,13 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
  * Backward of nerf_hip_forward (autograd through nerf.py:286-323, called at nerf.py:473).
  * Needs the workspace of a forward run with NERF_HIP_SAVE_FOR_BACKWARD and the same sizes/inputs.
  *   dC_coarse, dC_fine [B,3] f32   upstream gradients
- *   dweights24         HOST array of 24 DEVICE pointers, same shapes as weights24; OVERWRITTEN with
- *                      the gradients of this batch (sum over rays, no averaging)
+ *   ray0_near_far      as in nerf_hip_forward (must match the forward call)
+ *   dweights24         HOST array of 24 DEVICE pointers, same shapes as weights24 (16-byte aligned);
+ *                      OVERWRITTEN with the gradients of this batch (sum over rays, no averaging)
  */
 int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, const float* dC_fine,
-                      int B, int Nc, int Nf, float last_delta, float* const* dweights24,
-                      void* ws, size_t ws_bytes, int flags, void* stream);
+                      const float* ray0_near_far, int B, int Nc, int Nf, float last_delta,
+                      float* const* dweights24, void* ws, size_t ws_bytes, int flags, void* stream);
 
 /* ray_loss (nerf.py:325-331) and its gradient: loss[1] = sum (C_c-C*)^2 + sum (C_f-C*)^2,
  * dC_c = 2 (C_c - C*), dC_f = 2 (C_f - C*).  dC_* may be NULL. */
@@ -139,6 +145,13 @@ int nerf_hip_field(const float* const* weights24, const int64_t* row, const int6
 int nerf_hip_coarse_composite(const float* t_c, const float* sigma_c, const float* rgb_c, const float* near_far,
                               float delta0, int B, int Nc, int Nf, float* w_c, float* C_coarse, float* t_f,
                               uint32_t* status, void* stream);
+
+/* Backward of nerf_hip_coarse_composite (autograd through nerf.py:225-281): given dC_coarse[B,3] and the TOTAL
+ * d loss/d t_f [B,Nf], ADDS the gradients through C_coarse and through the inverse-CDF resampling to
+ * dsig_c[B,Nc] and drgb_c[B,Nc,3] (which already hold the contribution of the merged composite). */
+int nerf_hip_coarse_composite_backward(const float* t_c, const float* sigma_c, const float* rgb_c, const float* near_far,
+                                       float delta0, int B, int Nc, int Nf, const float* dC_coarse, const float* dt_f,
+                                       float* dsig_c, float* drgb_c, void* stream);
 
 /* Merge + per-channel sort + composite (nerf.py:302-321): in t_c/t_f, sigma_c/sigma_f, rgb_c/rgb_f;
  * out sorted bundle[B,Nc+Nf,5] (t,r,g,b,sigma; may be NULL), w[B,Nc+Nf] (may be NULL), C_fine[B,3]. */

@@ -5,3 +5,4 @@ nerf.py (host-side mirror of the reference's ``nerf`` module surface), ops.py (s
 """
 from . import _abi, ops  # noqa: F401
 from .nerf import NeRFModel, Network, Encoder  # noqa: F401
+HAS_BACKWARD = True

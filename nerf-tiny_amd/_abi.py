@@ -20,8 +20,9 @@ _PROTOS = {
     "nerf_hip_abi_version": (C.c_int, []),
     "nerf_hip_last_error": (C.c_char_p, []),
     "nerf_hip_ws_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "nerf_hip_ws_offset": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_size_t)]),
     "nerf_hip_forward": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, C.c_size_t, C.c_int, _p]),
-    "nerf_hip_backward": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_size_t, C.c_int, _p]),
+    "nerf_hip_backward": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_size_t, C.c_int, _p]),
     "nerf_hip_ray_loss": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, _p]),
     "nerf_hip_read_status": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_uint32), _p]),
     "nerf_hip_profile_begin": (C.c_int, [C.c_int]),
@@ -29,6 +30,7 @@ _PROTOS = {
     "nerf_hip_rays": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p]),
     "nerf_hip_field": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_size_t, _p]),
     "nerf_hip_coarse_composite": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
+    "nerf_hip_coarse_composite_backward": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
     "nerf_hip_merge_composite": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, _p]),
 }
 EXPORTS = tuple(_PROTOS)
@@ -84,6 +86,20 @@ def profile_end() -> dict:
     cnt = (C.c_int * n)()
     check(lib().nerf_hip_profile_end(ms, cnt, n))
     return {KERNEL_NAMES[i]: (ms[i], cnt[i]) for i in range(n) if cnt[i]}
+
+
+def ws_view(ws, B, Nc, Nf, flags, name, shape, dtype=None):
+    """A typed view of a named workspace buffer (tests / debugging)."""
+    import torch
+
+    off = C.c_size_t(0)
+    check(lib().nerf_hip_ws_offset(B, Nc, Nf, flags, name.encode(), C.byref(off)))
+    dtype = dtype or torch.float32
+    n = 1
+    for d in shape:
+        n *= d
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    return ws[off.value: off.value + nbytes].view(dtype).view(*shape)
 
 
 def ptr_array(tensors) -> "C.Array":

@@ -64,10 +64,22 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
     L.perm = take(b * 5 * N * 2);
     L.w_m = take(b * N * 4);
     L.bundle = take(b * N * 5 * 4);
-    L.save_c = take((size_t)10 * b * Nc * WIDTH * 4);
-    L.save_f = take((size_t)10 * b * Nf * WIDTH * 4);
-    L.spre_c = take(b * Nc * 4);
-    L.spre_f = take(b * Nf * 4);
+    const size_t Mtot = b * N;
+    const size_t tiles = (b * Nc + TM - 1) / TM + (b * Nf + TM - 1) / TM;
+    L.save = take((size_t)NSAVE * Mtot * WIDTH * 4);
+    L.masks = take((size_t)8 * tiles * 4 * 256 * 2);
+    L.spre = take(Mtot * 4);
+    L.G = take((size_t)NGRAD * Mtot * WIDTH * 4);
+    L.dz = take(Mtot * 16);
+    L.dspre = take(Mtot * 4);
+    L.drgb_c = take(b * Nc * 12);
+    L.dsig_c = take(b * Nc * 4);
+    L.drgb_f = take(b * Nf * 12);
+    L.dsig_f = take(b * Nf * 4);
+    L.dt_f = take(b * Nf * 4);
+    L.slabs = take(dw_slab_floats(256, 256) * 4);
+    L.sbuf = take(b * HALF * 4);
+    L.gdbuf = take(b * DIR_DIM * 4);
   }
   L.total = o;
   return L;
@@ -182,7 +194,11 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.rgb = at<float>(ws, L.rgb_c);
   fa.sigma = at<float>(ws, L.sig_c);
   fa.N = Nc; fa.M = B * Nc;
-  if (save) { fa.save = at<float>(ws, L.save_c); fa.spre = at<float>(ws, L.spre_c); }
+  const int tiles_c = (B * Nc + TM - 1) / TM, tiles_f = (B * Nf + TM - 1) / TM;
+  if (save) {
+    fa.save = at<float>(ws, L.save); fa.masks = at<uint16_t>(ws, L.masks); fa.spre = at<float>(ws, L.spre);
+    fa.row0 = 0; fa.tile0 = 0; fa.tiles_tot = tiles_c + tiles_f; fa.Mtot = (long long)B * (Nc + Nf);
+  }
   { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(launch_field_fwd(fa, save, st)); }
 
   CoarseArgs ca;
@@ -201,7 +217,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.rgb = at<float>(ws, L.rgb_f);
   fa.sigma = at<float>(ws, L.sig_f);
   fa.N = Nf; fa.M = B * Nf;
-  if (save) { fa.save = at<float>(ws, L.save_f); fa.spre = at<float>(ws, L.spre_f); }
+  if (save) { fa.row0 = B * Nc; fa.tile0 = tiles_c; }
   { ProfScope ps(NERF_HIP_K_FIELD_FINE, st); HIP_TRY(launch_field_fwd(fa, save, st)); }
 
   MergeArgs ma;
@@ -249,11 +265,124 @@ int nerf_hip_profile_end(double* ms_sum, int* count, int n_kernels) {
   return rc;
 }
 
-int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, const float* dC_fine, int B, int Nc, int Nf,
-                      float last_delta, float* const* dweights24, void* ws, size_t ws_bytes, int flags, void* stream) {
-  (void)weights24; (void)dC_coarse; (void)dC_fine; (void)B; (void)Nc; (void)Nf; (void)last_delta; (void)dweights24;
-  (void)ws; (void)ws_bytes; (void)flags; (void)stream;
-  return fail(NERF_HIP_ERR_ARG, "nerf_hip_backward: not built yet");
+int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, const float* dC_fine, const float* ray0_near_far,
+                      int B, int Nc, int Nf, float last_delta, float* const* dweights24, void* ws, size_t ws_bytes, int flags,
+                      void* stream) {
+  if (int rc = check_sizes(B, Nc, Nf)) return rc;
+  if (int rc = check_weights(weights24)) return rc;
+  if (int rc = check_weights(const_cast<const float* const*>(dweights24))) return rc;
+  if (!dC_coarse || !dC_fine || !ws) return fail(NERF_HIP_ERR_ARG, "null argument");
+  if (!(flags & NERF_HIP_SAVE_FOR_BACKWARD)) return fail(NERF_HIP_ERR_ARG, "backward needs a forward run with NERF_HIP_SAVE_FOR_BACKWARD");
+  const WsLayout L = layout(B, Nc, Nf, flags);
+  if (ws_bytes < L.total) return fail(NERF_HIP_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
+  if (int rc = check_device()) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Weights24 w = as_w24(weights24);
+  float* const* dw = dweights24;
+  const long long Mtot = (long long)B * (Nc + Nf);
+  const size_t MS = (size_t)Mtot * WIDTH;
+  const int tiles_c = (B * Nc + TM - 1) / TM, tiles_f = (B * Nf + TM - 1) / TM;
+  float* save = at<float>(ws, L.save);
+  float* G = at<float>(ws, L.G);
+
+  // 1. merged composite + per-channel sort backward (nerf.py:302-321)
+  MergeBwdArgs mb;
+  memset(&mb, 0, sizeof(mb));
+  mb.dC_f = dC_fine; mb.bundle = at<float>(ws, L.bundle); mb.perm = at<uint16_t>(ws, L.perm);
+  mb.B = B; mb.Nc = Nc; mb.Nf = Nf; mb.last = last_delta;
+  mb.drgb_c = at<float>(ws, L.drgb_c); mb.dsig_c = at<float>(ws, L.dsig_c);
+  mb.drgb_f = at<float>(ws, L.drgb_f); mb.dsig_f = at<float>(ws, L.dsig_f); mb.dt_f = at<float>(ws, L.dt_f);
+  { ProfScope ps(NERF_HIP_K_BWD_MERGE, st); HIP_TRY(launch_merge_bwd(mb, st)); }
+
+  // 2. fine-pass field backward (dX chain incl. d loss / d t_fine)
+  FieldBwdArgs fb;
+  memset(&fb, 0, sizeof(fb));
+  fb.wp = at<float4>(ws, L.packed); fb.w = w; fb.rayf = at<float>(ws, L.rayf);
+  fb.save = save; fb.masks = at<uint16_t>(ws, L.masks); fb.spre = at<float>(ws, L.spre);
+  fb.G = G; fb.dz = at<float>(ws, L.dz); fb.dspre = at<float>(ws, L.dspre);
+  fb.tiles_tot = tiles_c + tiles_f; fb.Mtot = Mtot;
+  fb.t = at<float>(ws, L.t_f); fb.rgb = at<float>(ws, L.rgb_f);
+  fb.drgb = at<float>(ws, L.drgb_f); fb.dsig = at<float>(ws, L.dsig_f); fb.dt = at<float>(ws, L.dt_f);
+  fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf;
+  { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st); HIP_TRY(launch_field_bwd(fb, true, st)); }
+
+  // 3. resampling + coarse composite backward (nerf.py:225-261, 263-281)
+  CoarseBwdArgs cb;
+  memset(&cb, 0, sizeof(cb));
+  cb.dC_c = dC_coarse; cb.dt_f = at<float>(ws, L.dt_f);
+  cb.t_c = at<float>(ws, L.t_c); cb.sigma = at<float>(ws, L.sig_c); cb.rgb = at<float>(ws, L.rgb_c);
+  cb.rayf = at<float>(ws, L.rayf);
+  cb.B = B; cb.Nc = Nc; cb.Nf = Nf;
+  if (ray0_near_far) { cb.ray0_override = 1; cb.near0 = ray0_near_far[0]; cb.far0 = ray0_near_far[1]; }
+  cb.drgb_c = at<float>(ws, L.drgb_c); cb.dsig_c = at<float>(ws, L.dsig_c);
+  { ProfScope ps(NERF_HIP_K_BWD_COARSE, st); HIP_TRY(launch_coarse_bwd(cb, st)); }
+
+  // 4. coarse-pass field backward
+  fb.t = at<float>(ws, L.t_c); fb.rgb = at<float>(ws, L.rgb_c);
+  fb.drgb = at<float>(ws, L.drgb_c); fb.dsig = at<float>(ws, L.dsig_c); fb.dt = nullptr;
+  fb.row0 = 0; fb.tile0 = 0; fb.N = Nc; fb.M = B * Nc;
+  { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st); HIP_TRY(launch_field_bwd(fb, false, st)); }
+
+  // 5. weight gradients: dW = G^T X over all B*(Nc+Nf) samples
+  {
+    ProfScope ps(NERF_HIP_K_BWD_DW, st);
+    DwProblem p;
+    memset(&p, 0, sizeof(p));
+    p.Mtot = Mtot; p.slabs = at<float>(ws, L.slabs); p.ldg = WIDTH; p.ldx = WIDTH;
+    // layer 0: X = gamma_p
+    p.G = G + 0 * MS; p.nout = 256; p.X = save + S_GP * MS; p.nin = 64; p.nin_real = POINT_DIM;
+    p.dW = dw[0]; p.ldw = POINT_DIM; p.col0 = 0; p.db = dw[1];
+    HIP_TRY(launch_dw(p, st));
+    for (int l = 1; l <= 7; ++l) {
+      p.G = G + (size_t)l * MS; p.X = save + (size_t)(l - 1) * MS; p.nin = 256; p.nin_real = 256;
+      p.dW = dw[2 * l]; p.ldw = (l == 4) ? WIDTH + POINT_DIM : WIDTH; p.col0 = 0; p.db = dw[2 * l + 1];
+      HIP_TRY(launch_dw(p, st));
+    }
+    // layer 4, skip columns
+    p.G = G + 4 * MS; p.X = save + S_GP * MS; p.nin = 64; p.nin_real = POINT_DIM;
+    p.dW = dw[8]; p.ldw = WIDTH + POINT_DIM; p.col0 = WIDTH; p.db = nullptr;
+    HIP_TRY(launch_dw(p, st));
+    // point_info
+    p.G = G + G_PI * MS; p.X = save + 7 * MS; p.nin = 256; p.nin_real = 256;
+    p.dW = dw[W_PI]; p.ldw = WIDTH; p.col0 = 0; p.db = dw[B_PI];
+    HIP_TRY(launch_dw(p, st));
+    // dir_info, feature columns
+    p.G = G + G_D * MS; p.nout = 128; p.X = save + S_FEAT * MS; p.nin = 256; p.nin_real = 256;
+    p.dW = dw[W_DIR]; p.ldw = WIDTH + DIR_DIM; p.col0 = DIR_DIM; p.db = dw[B_DIR];
+    HIP_TRY(launch_dw(p, st));
+    // thin heads
+    HIP_TRY(hipMemsetAsync(dw[W_SIGMA], 0, WIDTH * 4, st));
+    HIP_TRY(hipMemsetAsync(dw[B_SIGMA], 0, 4, st));
+    HIP_TRY(hipMemsetAsync(dw[W_COLOR], 0, 3 * HALF * 4, st));
+    HIP_TRY(hipMemsetAsync(dw[B_COLOR], 0, 3 * 4, st));
+    SmallGradArgs sg;
+    memset(&sg, 0, sizeof(sg));
+    sg.save = save; sg.G = G; sg.dz = at<float>(ws, L.dz); sg.dspre = at<float>(ws, L.dspre); sg.rayf = at<float>(ws, L.rayf);
+    sg.Mtot = Mtot; sg.B = B; sg.Nc = Nc; sg.Nf = Nf;
+    sg.dW_color = dw[W_COLOR]; sg.db_color = dw[B_COLOR]; sg.dw_sigma = dw[W_SIGMA]; sg.db_sigma = dw[B_SIGMA]; sg.dW_dir = dw[W_DIR];
+    sg.sbuf = at<float>(ws, L.sbuf); sg.gdbuf = at<float>(ws, L.gdbuf);
+    HIP_TRY(launch_small_grads(sg, st));
+  }
+  return NERF_HIP_OK;
+}
+
+int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_t* offset) {
+  if (!name || !offset) return fail(NERF_HIP_ERR_ARG, "null argument");
+  if (int rc = check_sizes(B, Nc, Nf)) return rc;
+  const WsLayout L = layout(B, Nc, Nf, flags);
+  struct { const char* n; size_t o; } tab[] = {
+      {"status", L.status}, {"packed", L.packed}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
+      {"rgb_c", L.rgb_c}, {"w_c", L.w_c}, {"t_f", L.t_f}, {"sig_f", L.sig_f}, {"rgb_f", L.rgb_f}, {"perm", L.perm},
+      {"w_m", L.w_m}, {"bundle", L.bundle}, {"save", L.save}, {"masks", L.masks}, {"spre", L.spre}, {"G", L.G}, {"dz", L.dz},
+      {"dspre", L.dspre}, {"drgb_c", L.drgb_c}, {"dsig_c", L.dsig_c}, {"drgb_f", L.drgb_f}, {"dsig_f", L.dsig_f},
+      {"dt_f", L.dt_f}, {"slabs", L.slabs}, {"masks", L.masks}};
+  for (auto& e : tab)
+    if (strcmp(e.n, name) == 0) {
+      if (e.o == 0 && strcmp(name, "status") != 0) return fail(NERF_HIP_ERR_ARG, "buffer %s is not part of this layout (flags=%d)", name, flags);
+      *offset = e.o;
+      return NERF_HIP_OK;
+    }
+  return fail(NERF_HIP_ERR_ARG, "unknown workspace buffer %s", name);
 }
 
 int nerf_hip_ray_loss(const float* C_coarse, const float* C_fine, const float* C_true, int B, float* loss, float* dC_coarse,
@@ -330,6 +459,20 @@ int nerf_hip_coarse_composite(const float* t_c, const float* sigma_c, const floa
   ca.delta0_mode = 1; ca.delta0 = delta0;
   ca.w_c = w_c; ca.C_coarse = C_coarse; ca.t_f = t_f; ca.status = status;
   HIP_TRY(launch_coarse(ca, static_cast<hipStream_t>(stream)));
+  return NERF_HIP_OK;
+}
+
+int nerf_hip_coarse_composite_backward(const float* t_c, const float* sigma_c, const float* rgb_c, const float* near_far,
+                                       float delta0, int B, int Nc, int Nf, const float* dC_coarse, const float* dt_f,
+                                       float* dsig_c, float* drgb_c, void* stream) {
+  if (!t_c || !sigma_c || !rgb_c || !near_far || !dC_coarse || !dt_f || !dsig_c || !drgb_c) return fail(NERF_HIP_ERR_ARG, "null argument");
+  if (B < 1 || Nc < 2 || Nc > 1024 || Nf < 1 || Nf > 1024) return fail(NERF_HIP_ERR_ARG, "bad sizes");
+  CoarseBwdArgs cb;
+  memset(&cb, 0, sizeof(cb));
+  cb.dC_c = dC_coarse; cb.dt_f = dt_f; cb.t_c = t_c; cb.sigma = sigma_c; cb.rgb = rgb_c; cb.near_far = near_far;
+  cb.B = B; cb.Nc = Nc; cb.Nf = Nf; cb.delta0_mode = 1; cb.delta0 = delta0;
+  cb.drgb_c = drgb_c; cb.dsig_c = dsig_c;
+  HIP_TRY(launch_coarse_bwd(cb, static_cast<hipStream_t>(stream)));
   return NERF_HIP_OK;
 }
 

@@ -1,0 +1,146 @@
+// field_common.h -- device building blocks shared by the fused field kernels (forward and backward chain).
+#pragma once
+#include "kernels.h"
+
+namespace nerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// building blocks of the fused kernels
+// ------------------------------------------------------------------------------------------
+
+// acc[f][st] += W[ft0+f tile][k] * act[st*32 + sample][k]  for k in [0, 8*KB)
+template <int KB, int NFT>
+__device__ __forceinline__ void mfma_layer(const float4* __restrict__ wseg, int ft0, const float* act, int kcol0, int lane,
+                                           f32x16 (&acc)[NFT][2]) {
+  const int j = lane & 31, h = lane >> 5;
+  const float* a0p = act + j * LDA + kcol0 + 4 * h;
+  const float* a1p = a0p + 32 * LDA;
+  const float4* wbase = wseg + (size_t)ft0 * KB * 64 + lane;
+  float4 wc[NFT], wn[NFT];
+#pragma unroll
+  for (int f = 0; f < NFT; ++f) wc[f] = wbase[(size_t)f * KB * 64];
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    const int kn = (kb + 1 < KB) ? kb + 1 : kb;
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) wn[f] = wbase[(size_t)(f * KB + kn) * 64];
+    const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
+    const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) {
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].x, a0.x, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].x, a1.x, acc[f][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) {
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].y, a0.y, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].y, a1.y, acc[f][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) {
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].z, a0.z, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].z, a1.z, acc[f][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) {
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].w, a0.w, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].w, a1.w, acc[f][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) wc[f] = wn[f];
+  }
+}
+
+// accumulators <- bias (feature = fbase + f*32 + 8g + 4h + r for register 4g + r)
+template <int NFT>
+__device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, int fbase, int lane, f32x16 (&acc)[NFT][2]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int f = 0; f < NFT; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + fbase + f * 32 + 8 * g + 4 * h);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        acc[f][st][4 * g + 0] = b.x;
+        acc[f][st][4 * g + 1] = b.y;
+        acc[f][st][4 * g + 2] = b.z;
+        acc[f][st][4 * g + 3] = b.w;
+      }
+    }
+}
+
+// accumulators -> LDS activation rows (optionally through ReLU).  mask (training): one uint16 per (f, st) tile and
+// lane, bit 4g+r = accumulator register 4g+r was > 0; stored at mask[(f*2+st)*256] (caller offsets by thread).
+template <int NFT, bool RELU>
+__device__ __forceinline__ void acc_store(float* act, int fbase, int lane, const f32x16 (&acc)[NFT][2], uint16_t* mask = nullptr) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int f = 0; f < NFT; ++f)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      if (RELU && mask) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= (acc[f][st][r] > 0.f) ? (1u << r) : 0u;
+        mask[(f * 2 + st) * 256] = (uint16_t)bits;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(acc[f][st][4 * g], acc[f][st][4 * g + 1], acc[f][st][4 * g + 2], acc[f][st][4 * g + 3]);
+        if (RELU) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(act + (st * 32 + j) * LDA + fbase + f * 32 + 8 * g + 4 * h) = v;
+      }
+    }
+}
+
+// world point of a sample: v = d_cam * t; p = ((R0*v0 + R1*v1) + R2*v2) + o   (nerf.py:200-216; every product
+// and sum rounded separately -- the translation unit is built with -ffp-contract=off)
+__device__ __forceinline__ void sample_point(const float* __restrict__ rf, float t, float (&p)[3]) {
+  const float v0 = rf[RF_DCAM + 0] * t, v1 = rf[RF_DCAM + 1] * t, v2 = rf[RF_DCAM + 2] * t;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) p[c] = ((rf[RF_R + 3 * c] * v0 + rf[RF_R + 3 * c + 1] * v1) + rf[RF_R + 3 * c + 2] * v2) + rf[RF_O + c];
+}
+
+// gamma_p of this thread's sample -> act[sm][0..63] (cols 60..63 = 0).  Wave wv writes (c,l) pairs 8wv .. 8wv+7.
+// gamma[c*20 + 2l + s] = (sin, cos)[s](fp32(x_c * f_l))   (nerf.py:135-167, flatten nerf.py:103)
+__device__ __forceinline__ void encode_point_to_lds(const float (&p)[3], float* act, int sm, int wv) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = wv * 8 + i;  // wave-uniform
+    float2 sc = make_float2(0.f, 0.f);
+    int col;
+    if (e < 30) {
+      const int c = e / 10, l = e - 10 * c;
+      const float x = (c == 0) ? p[0] : ((c == 1) ? p[1] : p[2]);
+      const float ph = x * __uint_as_float(kFreqPointBits[l]);
+      sc.x = sinf(ph);
+      sc.y = cosf(ph);
+      col = c * 20 + 2 * l;
+    } else {
+      col = 60 + 2 * (e - 30);
+    }
+    *reinterpret_cast<float2*>(act + sm * LDA + col) = sc;
+  }
+}
+
+// copy act[0..63][0 .. 4*ncol4) to rows [grow0, grow0 + nrows) of a row-major global buffer with row stride ldd
+__device__ __forceinline__ void save_rows(const float* act, float* __restrict__ dst, long long grow0, int nrows, int ncol4, int ldd, int tid) {
+  for (int idx = tid; idx < TM * ncol4; idx += 256) {
+    const int r = idx / ncol4, c4 = idx - r * ncol4;
+    if (r < nrows) {
+      const float4 v = *reinterpret_cast<const float4*>(act + r * LDA + 4 * c4);
+      *reinterpret_cast<float4*>(dst + (size_t)(grow0 + r) * ldd + 4 * c4) = v;
+    }
+  }
+}
+
+
+}  // namespace nerf

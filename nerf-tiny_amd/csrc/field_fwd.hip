@@ -17,11 +17,10 @@
 //    all 2.36 MB of weights fit every XCD's 4 MiB L2); the next k-block's fragment is prefetched
 //    behind the current block's 16 MFMAs (1024 cycles), which hides the L2 latency;
 //  * two workgroups per CU (2 x 68 KiB LDS): one's barriers/epilogues hide under the other's MFMAs.
-#include "kernels.h"
+#include "field_common.h"
 
 namespace nerf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 
@@ -90,136 +89,6 @@ __global__ void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg) 
 }
 
 // ------------------------------------------------------------------------------------------
-// building blocks of the fused kernels
-// ------------------------------------------------------------------------------------------
-
-// acc[f][st] += W[ft0+f tile][k] * act[st*32 + sample][k]  for k in [0, 8*KB)
-template <int KB, int NFT>
-__device__ __forceinline__ void mfma_layer(const float4* __restrict__ wseg, int ft0, const float* act, int kcol0, int lane,
-                                           f32x16 (&acc)[NFT][2]) {
-  const int j = lane & 31, h = lane >> 5;
-  const float* a0p = act + j * LDA + kcol0 + 4 * h;
-  const float* a1p = a0p + 32 * LDA;
-  const float4* wbase = wseg + (size_t)ft0 * KB * 64 + lane;
-  float4 wc[NFT], wn[NFT];
-#pragma unroll
-  for (int f = 0; f < NFT; ++f) wc[f] = wbase[(size_t)f * KB * 64];
-#pragma unroll 2
-  for (int kb = 0; kb < KB; ++kb) {
-    const int kn = (kb + 1 < KB) ? kb + 1 : kb;
-#pragma unroll
-    for (int f = 0; f < NFT; ++f) wn[f] = wbase[(size_t)(f * KB + kn) * 64];
-    const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
-    const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
-#pragma unroll
-    for (int f = 0; f < NFT; ++f) {
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].x, a0.x, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].x, a1.x, acc[f][1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int f = 0; f < NFT; ++f) {
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].y, a0.y, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].y, a1.y, acc[f][1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int f = 0; f < NFT; ++f) {
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].z, a0.z, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].z, a1.z, acc[f][1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int f = 0; f < NFT; ++f) {
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].w, a0.w, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].w, a1.w, acc[f][1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int f = 0; f < NFT; ++f) wc[f] = wn[f];
-  }
-}
-
-// accumulators <- bias (feature = fbase + f*32 + 8g + 4h + r for register 4g + r)
-template <int NFT>
-__device__ __forceinline__ void acc_init_bias(const float* __restrict__ bias, int fbase, int lane, f32x16 (&acc)[NFT][2]) {
-  const int h = lane >> 5;
-#pragma unroll
-  for (int f = 0; f < NFT; ++f)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 b = *reinterpret_cast<const float4*>(bias + fbase + f * 32 + 8 * g + 4 * h);
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        acc[f][st][4 * g + 0] = b.x;
-        acc[f][st][4 * g + 1] = b.y;
-        acc[f][st][4 * g + 2] = b.z;
-        acc[f][st][4 * g + 3] = b.w;
-      }
-    }
-}
-
-// accumulators -> LDS activation rows (optionally through ReLU)
-template <int NFT, bool RELU>
-__device__ __forceinline__ void acc_store(float* act, int fbase, int lane, const f32x16 (&acc)[NFT][2]) {
-  const int j = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int f = 0; f < NFT; ++f)
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(acc[f][st][4 * g], acc[f][st][4 * g + 1], acc[f][st][4 * g + 2], acc[f][st][4 * g + 3]);
-        if (RELU) {
-          v.x = fmaxf(v.x, 0.f);
-          v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f);
-          v.w = fmaxf(v.w, 0.f);
-        }
-        *reinterpret_cast<float4*>(act + (st * 32 + j) * LDA + fbase + f * 32 + 8 * g + 4 * h) = v;
-      }
-}
-
-// world point of a sample: v = d_cam * t; p = ((R0*v0 + R1*v1) + R2*v2) + o   (nerf.py:200-216; every product
-// and sum rounded separately -- the translation unit is built with -ffp-contract=off)
-__device__ __forceinline__ void sample_point(const float* __restrict__ rf, float t, float (&p)[3]) {
-  const float v0 = rf[RF_DCAM + 0] * t, v1 = rf[RF_DCAM + 1] * t, v2 = rf[RF_DCAM + 2] * t;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) p[c] = ((rf[RF_R + 3 * c] * v0 + rf[RF_R + 3 * c + 1] * v1) + rf[RF_R + 3 * c + 2] * v2) + rf[RF_O + c];
-}
-
-// gamma_p of this thread's sample -> act[sm][0..63] (cols 60..63 = 0).  Wave wv writes (c,l) pairs 8wv .. 8wv+7.
-// gamma[c*20 + 2l + s] = (sin, cos)[s](fp32(x_c * f_l))   (nerf.py:135-167, flatten nerf.py:103)
-__device__ __forceinline__ void encode_point_to_lds(const float (&p)[3], float* act, int sm, int wv) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = wv * 8 + i;  // wave-uniform
-    float2 sc = make_float2(0.f, 0.f);
-    int col;
-    if (e < 30) {
-      const int c = e / 10, l = e - 10 * c;
-      const float x = (c == 0) ? p[0] : ((c == 1) ? p[1] : p[2]);
-      const float ph = x * __uint_as_float(kFreqPointBits[l]);
-      sc.x = sinf(ph);
-      sc.y = cosf(ph);
-      col = c * 20 + 2 * l;
-    } else {
-      col = 60 + 2 * (e - 30);
-    }
-    *reinterpret_cast<float2*>(act + sm * LDA + col) = sc;
-  }
-}
-
-// copy act[0..63][0..ncol) to a row-major global buffer dst[m0 + r][ldd]
-__device__ __forceinline__ void save_rows(const float* act, float* __restrict__ dst, int m0, int M, int ncol4, int ldd, int tid) {
-  // ncol4 = columns / 4 (64 or 32); threads sweep rows
-  const int per_row = ncol4;
-  for (int idx = tid; idx < TM * per_row; idx += 256) {
-    const int r = idx / per_row, c4 = idx - r * per_row;
-    if (m0 + r < M) {
-      const float4 v = *reinterpret_cast<const float4*>(act + r * LDA + 4 * c4);
-      *reinterpret_cast<float4*>(dst + (size_t)(m0 + r) * ldd + 4 * c4) = v;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // the fused forward kernel
 // ------------------------------------------------------------------------------------------
 template <bool SAVE>
@@ -236,6 +105,11 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   const int mc = valid ? m : a.M - 1;
   const int ray = mc / a.N;
   const float* rf = a.rayf + (size_t)ray * RAYF;
+  const int nrows = (a.M - m0) < TM ? (a.M - m0) : TM;  // live rows of this tile
+  const long long grow0 = (long long)a.row0 + m0;       // first row in the combined (coarse|fine) buffers
+  const size_t MS = (size_t)a.Mtot * WIDTH;              // stride between saved tensors
+  uint16_t* mk = SAVE ? a.masks + ((size_t)(a.tile0 + blockIdx.x) * 4) * 256 + tid : nullptr;
+  const size_t MKS = (size_t)a.tiles_tot * 4 * 256;      // stride between mask layers
 
   float p[3];
   sample_point(rf, a.t[mc], p);
@@ -253,28 +127,28 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
     }
   }
 
+  if (SAVE) save_rows(act, a.save + S_GP * MS, grow0, nrows, 16, WIDTH, tid);
+
   f32x16 acc[2][2];
   const int fbase = wv * 64;
-  const size_t MS = (size_t)a.M * WIDTH;  // stride between saved layers
 
   // ---- layer 0: 60(64) -> 256
   acc_init_bias<2>(a.w.p[B_L0], fbase, lane, acc);
   mfma_layer<8, 2>(a.wp + seg_off4(SEG_L0), wv * 2, act, 0, lane, acc);
   __syncthreads();
-  acc_store<2, true>(act, fbase, lane, acc);
+  acc_store<2, true>(act, fbase, lane, acc, mk);
   __syncthreads();
-  if (SAVE) save_rows(act, a.save + 0 * MS, m0, a.M, 64, WIDTH, tid);
+  if (SAVE) save_rows(act, a.save + 0 * MS, grow0, nrows, 64, WIDTH, tid);
 
   // ---- layers 1..3
 #pragma unroll 1
   for (int l = 1; l <= 3; ++l) {
     acc_init_bias<2>(a.w.p[2 * l + 1], fbase, lane, acc);
-    mfma_layer<32, 2>(a.wp + seg_off4(SEG_L0) + seg_nft(SEG_L0) * seg_kb(SEG_L0) * 64 + (size_t)(l - 1) * 8 * 32 * 64, wv * 2, act, 0,
-                      lane, acc);
+    mfma_layer<32, 2>(a.wp + seg_off4(SEG_L1) + (size_t)(l - 1) * 8 * 32 * 64, wv * 2, act, 0, lane, acc);
     __syncthreads();
-    acc_store<2, true>(act, fbase, lane, acc);
+    acc_store<2, true>(act, fbase, lane, acc, SAVE ? mk + l * MKS : nullptr);
     __syncthreads();
-    if (SAVE) save_rows(act, a.save + (size_t)l * MS, m0, a.M, 64, WIDTH, tid);
+    if (SAVE) save_rows(act, a.save + (size_t)l * MS, grow0, nrows, 64, WIDTH, tid);
   }
 
   // ---- layer 4: cat(h3, gamma_p) (hidden first, nerf.py:109) -> 256
@@ -285,9 +159,9 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   __syncthreads();
   mfma_layer<8, 2>(a.wp + seg_off4(SEG_L4B), wv * 2, act, 0, lane, acc);
   __syncthreads();
-  acc_store<2, true>(act, fbase, lane, acc);
+  acc_store<2, true>(act, fbase, lane, acc, SAVE ? mk + 4 * MKS : nullptr);
   __syncthreads();
-  if (SAVE) save_rows(act, a.save + 4 * MS, m0, a.M, 64, WIDTH, tid);
+  if (SAVE) save_rows(act, a.save + 4 * MS, grow0, nrows, 64, WIDTH, tid);
 
   // ---- layers 5..7
 #pragma unroll 1
@@ -295,9 +169,9 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
     acc_init_bias<2>(a.w.p[2 * l + 1], fbase, lane, acc);
     mfma_layer<32, 2>(a.wp + seg_off4(SEG_L5) + (size_t)(l - 5) * 8 * 32 * 64, wv * 2, act, 0, lane, acc);
     __syncthreads();
-    acc_store<2, true>(act, fbase, lane, acc);
+    acc_store<2, true>(act, fbase, lane, acc, SAVE ? mk + l * MKS : nullptr);
     __syncthreads();
-    if (SAVE) save_rows(act, a.save + (size_t)l * MS, m0, a.M, 64, WIDTH, tid);
+    if (SAVE) save_rows(act, a.save + (size_t)l * MS, grow0, nrows, 64, WIDTH, tid);
   }
 
   // ---- sigma head (VALU): sigma = |w_sigma . h7 + b|   (nerf.py:94, 115)
@@ -323,11 +197,11 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   if (wv == 0 && valid) {
     const float pre = ((scr[sm] + scr[64 + sm]) + (scr[128 + sm] + scr[192 + sm])) + a.w.p[B_SIGMA][0];
     a.sigma[m] = fabsf(pre);
-    if (SAVE) a.spre[m] = pre;
+    if (SAVE) a.spre[a.row0 + m] = pre;
   }
   acc_store<2, false>(act, fbase, lane, acc);
   __syncthreads();
-  if (SAVE) save_rows(act, a.save + 8 * MS, m0, a.M, 64, WIDTH, tid);
+  if (SAVE) save_rows(act, a.save + S_FEAT * MS, grow0, nrows, 64, WIDTH, tid);
 
   // ---- dir_info: cat(gamma_d, feat) -> 128, ReLU (nerf.py:98, 118).  The gamma_d part (+ bias) is per ray: dvec.
   f32x16 acd[1][2];
@@ -352,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   __syncthreads();
   acc_store<1, true>(act, wv * 32, lane, acd);
   __syncthreads();
-  if (SAVE) save_rows(act, a.save + 9 * MS, m0, a.M, 32, WIDTH, tid);
+  if (SAVE) save_rows(act, a.save + S_C * MS, grow0, nrows, 32, WIDTH, tid);
 
   // ---- colour head (VALU): rgb = sigmoid(W_c c + b)   (nerf.py:99, 119)
   {

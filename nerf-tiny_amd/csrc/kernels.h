@@ -17,11 +17,21 @@ struct FieldArgs {
   float* sigma;            // [M]
   float* pts_dbg;          // [M][3] or null
   float* gp_dbg;           // [M][60] or null
-  float* save;             // training: [10][M][256] (h0..h7, feat, c(128 used)) or null
-  float* spre;             // training: [M] sigma pre-activation
+  // ---- training only (SAVE): rows of the coarse pass come first, then the fine pass, in every buffer
+  float* save;             // [NSAVE][Mtot][256]: h0..h7, feat, c (128 used), gamma_p (64 used)
+  uint16_t* masks;         // [8][tiles_tot][4][256]: ReLU masks of h0..h7 in accumulator layout
+  float* spre;             // [Mtot] sigma pre-activation
+  int row0;                // first row of this pass in the combined buffers
+  int tile0;               // first tile of this pass in the mask buffer
+  int tiles_tot;
+  long long Mtot;
   int N;                   // samples per ray
-  int M;                   // total samples (B*N)
+  int M;                   // samples of this pass (B*N)
 };
+
+constexpr int S_H0 = 0, S_FEAT = 8, S_C = 9, S_GP = 10, NSAVE = 11;
+// gradient buffers written by the backward chain: dpre of layers 0..7, of point_info (= dfeat), of dir_info
+constexpr int G_L0 = 0, G_PI = 8, G_D = 9, NGRAD = 10;
 
 struct RaysArgs {
   const int64_t* row;
@@ -72,5 +82,85 @@ hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st);
 size_t merge_lds_bytes(int P);
 hipError_t launch_merge(const MergeArgs& a, hipStream_t st);
 hipError_t launch_ray_loss(const float* Cc, const float* Cf, const float* Ct, int B, float* loss, float* dCc, float* dCf, hipStream_t st);
+
+}  // namespace nerf
+
+// ================================================================================================
+// backward
+// ================================================================================================
+namespace nerf {
+
+struct FieldBwdArgs {
+  const float4* wp;        // packed weights incl. transposed segments
+  Weights24 w;
+  const float* rayf;       // [B][RAYF]
+  const float* t;          // [M] depths of this pass
+  const float* rgb;        // [M][3] forward output of this pass
+  const float* drgb;       // [M][3] upstream gradient
+  const float* dsig;       // [M]    upstream gradient
+  const float* save;       // [NSAVE][Mtot][256]
+  const uint16_t* masks;   // [8][tiles_tot][4][256]
+  const float* spre;       // [Mtot]
+  float* G;                // [NGRAD][Mtot][256] pre-activation gradients (inputs of the dW GEMMs)
+  float* dz;               // [Mtot][4] colour-head pre-sigmoid gradient
+  float* dspre;            // [Mtot]    sigma-head pre-abs gradient
+  float* dt;               // [M] fine pass only: in = d loss/d t from the merge, out += direction . d loss/d point
+  int row0, tile0, tiles_tot;
+  long long Mtot;
+  int N, M;
+};
+
+struct DwProblem {
+  const float* G; int ldg; int nout;      // [Mtot][ldg]; nout = 256 or 128
+  const float* X; int ldx; int nin;       // [Mtot][ldx]; nin  = 256 or 64 (padded)
+  float* dW; int ldw; int col0; int nin_real;  // destination [nout][ldw], columns col0 .. col0 + nin_real
+  float* db;                              // [nout] bias gradient (column sums of G) or null
+  long long Mtot;
+  float* slabs;                           // scratch: nslabs * (nout*nin + nout) floats
+};
+constexpr int DW_WGS = 256;  // one workgroup per CU
+
+struct MergeBwdArgs {
+  const float* dC_f;       // [B][3]
+  const float* bundle;     // [B][N][5] sorted channels
+  const uint16_t* perm;    // [B][5][N]
+  int B, Nc, Nf;
+  float last;
+  float *drgb_c, *dsig_c;  // [B][Nc][3], [B][Nc]   (written: contribution through the merged composite)
+  float *drgb_f, *dsig_f, *dt_f;  // [B][Nf][3], [B][Nf], [B][Nf]
+};
+
+struct CoarseBwdArgs {
+  const float* dC_c;       // [B][3]
+  const float* dt_f;       // [B][Nf] total d loss / d t_fine
+  const float *t_c, *sigma, *rgb;  // coarse forward values
+  const float* rayf;       // [B][RAYF] or null (then near_far is used)
+  const float* near_far;   // [B][2] or null
+  int B, Nc, Nf;
+  int delta0_mode; float delta0;   // as CoarseArgs
+  int ray0_override; float near0, far0;
+  float *drgb_c, *dsig_c;  // in: merge contribution, out: total
+};
+
+struct SmallGradArgs {
+  const float* save;       // saves base
+  const float* G;          // grads base
+  const float* dz;         // [Mtot][4]
+  const float* dspre;      // [Mtot]
+  const float* rayf;
+  long long Mtot;
+  int B, Nc, Nf;
+  float *dW_color, *db_color, *dw_sigma, *db_sigma, *dW_dir;  // destinations (dW_dir: [128][280], cols 0..23 written)
+  float* sbuf;             // [B][128] scratch: per-ray sums of dpre_dir
+  float* gdbuf;            // [B][24]  scratch: gamma_dir per ray
+};
+
+hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st);
+hipError_t launch_dw(const DwProblem& p, hipStream_t st);
+size_t dw_slab_floats(int nout, int nin);
+hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st);
+size_t merge_bwd_lds_bytes(int N);
+hipError_t launch_merge_bwd(const MergeBwdArgs& a, hipStream_t st);
+hipError_t launch_coarse_bwd(const CoarseBwdArgs& a, hipStream_t st);
 
 }  // namespace nerf

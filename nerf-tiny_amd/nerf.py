@@ -72,10 +72,9 @@ class ResampleIndexError(RuntimeError):
 
 class _RenderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, row, col, pb, K9, ray0, *params):
+    def forward(ctx, model, need_grad, row, col, pb, K9, ray0, *params):
         B = row.shape[0]
         Nc, Nf = model.num_coarse, model.num_fine
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         flags = _abi.SAVE_FOR_BACKWARD if need_grad else 0
         ws = model._workspace(B, flags)
         dev = row.device
@@ -90,7 +89,7 @@ class _RenderFn(torch.autograd.Function):
             model._ws_generation += 1
             ctx.generation = model._ws_generation
             ctx.model, ctx.ws, ctx.flags, ctx.B = model, ws, flags, B
-            ctx.params = params
+            ctx.params, ctx.ray0 = params, ray0
         return C_c, C_f
 
     @staticmethod
@@ -103,10 +102,10 @@ class _RenderFn(torch.autograd.Function):
         dC_c = dC_c.contiguous().float()
         dC_f = dC_f.contiguous().float()
         stream = torch.cuda.current_stream(dC_c.device).cuda_stream
-        _abi.check(_abi.lib().nerf_hip_backward(_abi.ptr_array(params), dC_c.data_ptr(), dC_f.data_ptr(), ctx.B,
+        _abi.check(_abi.lib().nerf_hip_backward(_abi.ptr_array(params), dC_c.data_ptr(), dC_f.data_ptr(), ctx.ray0, ctx.B,
                                                 model.num_coarse, model.num_fine, LAST_DELTA, _abi.ptr_array(grads),
                                                 ctx.ws.data_ptr(), ctx.ws.numel(), ctx.flags, stream))
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class NeRFModel(nn.Module):
@@ -169,7 +168,8 @@ class NeRFModel(nn.Module):
         row_d = row.to(dev, torch.int64).contiguous()
         col_d = column.to(dev, torch.int64).contiguous()
         ray0 = _abi.f32_array(self.ray0_near_far) if self.ray0_near_far is not None else None
-        C_c, C_f = _RenderFn.apply(self, row_d, col_d, pb, K9, ray0, *ps)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in ps)  # grad mode is off inside Function.forward
+        C_c, C_f = _RenderFn.apply(self, need_grad, row_d, col_d, pb, K9, ray0, *ps)
         if self.check_resample:
             st = C.c_uint32(0)
             ws = next(iter(self._ws.values()))
@@ -186,7 +186,7 @@ class _RayLossFn(torch.autograd.Function):
         C_c, C_f, C_t = C_c.contiguous(), C_f.contiguous(), C_t.contiguous().to(C_c.device, torch.float32)
         B = C_c.shape[0]
         loss = torch.empty(1, dtype=torch.float32, device=C_c.device)
-        need = torch.is_grad_enabled() and (C_c.requires_grad or C_f.requires_grad)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dCc = torch.empty_like(C_c) if need else None
         dCf = torch.empty_like(C_f) if need else None
         _abi.check(_abi.lib().nerf_hip_ray_loss(C_c.data_ptr(), C_f.data_ptr(), C_t.data_ptr(), B, loss.data_ptr(),

@@ -73,3 +73,18 @@ def merge_composite(t_c, t_f, sigma_c, sigma_f, rgb_c, rgb_f, last=1e-4):
                                                    rgb_c.contiguous().data_ptr(), rgb_f.contiguous().data_ptr(), B, Nc, Nf,
                                                    float(last), bundle.data_ptr(), w.data_ptr(), C_f.data_ptr(), _stream(t_c)))
     return bundle, w, C_f
+
+
+def coarse_composite_backward(t_c, sigma_c, rgb_c, near, far, delta0, dC_c, dt_f):
+    """-> dsig_c[B,Nc], drgb_c[B,Nc,3] (contributions through C_coarse and the resampled depths)"""
+    B, Nc = t_c.shape
+    Nf = dt_f.shape[1]
+    dev = t_c.device
+    nf = torch.stack((near, far), dim=1).contiguous().to(dev)
+    dsig = torch.zeros(B, Nc, device=dev)
+    drgb = torch.zeros(B, Nc, 3, device=dev)
+    _abi.check(_abi.lib().nerf_hip_coarse_composite_backward(t_c.contiguous().data_ptr(), sigma_c.contiguous().data_ptr(),
+                                                             rgb_c.contiguous().data_ptr(), nf.data_ptr(), float(delta0), B, Nc, Nf,
+                                                             dC_c.contiguous().data_ptr(), dt_f.contiguous().data_ptr(),
+                                                             dsig.data_ptr(), drgb.data_ptr(), _stream(t_c)))
+    return dsig, drgb

@@ -24,6 +24,22 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+def host_fingerprint() -> str:
+    """CPU model + torch/numpy versions + thread count.  GEMM-dependent golden values are bit-reproducible only on the
+    host class that generated them (oneDNN/MKL pick kernels per CPU and thread count); everything upstream of the first
+    GEMM (rays, depths, points, encodings) is bit-reproducible everywhere."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return f"{model} | torch {torch.__version__} | numpy {np.__version__} | threads {torch.get_num_threads()}"
+
+
 # --------------------------------------------------------------------------------------
 # parameters
 # --------------------------------------------------------------------------------------

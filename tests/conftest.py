@@ -21,7 +21,7 @@ def pytest_configure(config):
 def oracle():
     import nerf_oracle
 
-    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))  # the fixtures were generated with 8 threads
     return nerf_oracle
 
 

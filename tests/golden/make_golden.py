@@ -112,7 +112,7 @@ def case(name, inputs, seed, sharp, Nc, Nf, store_full_grads, stage_rays=8):
     ok &= check_equal("gp_c", st["gp_c"], O.encode(ost["pts_c"], O.frequencies()[0]))
     assert ok, f"oracle restatement is NOT bit-identical to the reference on case {name}"
     assert gmax < 1e-5
-    out = dict(row=row.numpy(), col=col.numpy(), poses_bound=pb.numpy(), K_inv=K_inv.numpy(), C_true=C_true.numpy(),
+    out = dict(meta_host=np.array(O.host_fingerprint()), row=row.numpy(), col=col.numpy(), poses_bound=pb.numpy(), K_inv=K_inv.numpy(), C_true=C_true.numpy(),
                seed=np.int64(seed), sharp=np.bool_(sharp), Nc=np.int64(Nc), Nf=np.int64(Nf),
                C_coarse=Cc.numpy(), C_fine=Cf.numpy(), loss=loss.numpy())
     s = slice(0, stage_rays)
