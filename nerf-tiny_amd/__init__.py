@@ -3,6 +3,6 @@
 Layout:  csrc/ (HIP kernels + C ABI -> libnerf_hip.so), _abi.py (ctypes binding),
 nerf.py (host-side mirror of the reference's ``nerf`` module surface), ops.py (stage-level calls).
 """
-from . import _abi, ops  # noqa: F401
+from . import _abi, ops, parallel  # noqa: F401
 from .nerf import NeRFModel, Network, Encoder  # noqa: F401
 HAS_BACKWARD = True

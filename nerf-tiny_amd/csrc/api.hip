@@ -77,7 +77,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
     L.drgb_f = take(b * Nf * 12);
     L.dsig_f = take(b * Nf * 4);
     L.dt_f = take(b * Nf * 4);
-    L.slabs = take(dw_slab_floats(256, 256) * 4);
+    L.slabs = take(dw_slab_floats_max() * 4);
     L.sbuf = take(b * HALF * 4);
     L.gdbuf = take(b * DIR_DIM * 4);
   }

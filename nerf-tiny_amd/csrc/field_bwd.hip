@@ -236,94 +236,121 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // weight-gradient GEMM
 // ------------------------------------------------------------------------------------------------
-template <int CB> struct VecB;
-template <> struct VecB<4> { typedef float4 T; };
-template <> struct VecB<2> { typedef float2 T; };
-
 __device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 __device__ __forceinline__ float comp(const float2& v, int c) { return c == 0 ? v.x : v.y; }
 
-constexpr int DW_UNROLL = 4;  // k-steps (row pairs) per pipeline stage
+constexpr int DW_UNROLL = 4;   // k-steps (row pairs) per pipeline stage
+constexpr int DW_STAGES = 3;   // register stages in flight (2 prefetched ahead of the one being multiplied)
+constexpr int DW_CB = 2;       // B components per lane: a wave owns a 128 (out) x 64 (in) block
+constexpr int DW_WAVES = 8;    // 512 threads, two waves per SIMD
 
-// Slab layout per wave: [cA 4][cB CB][reg 16][lane 64] floats, then (if bias) [128] column sums of this wave's out block.
-template <int CB>
-__global__ __launch_bounds__(256, 1) void k_dw(const DwProblem p) {
-  typedef typename VecB<CB>::T BV;
+struct DwStage {
+  float4 a[DW_UNROLL];
+  float2 b[DW_UNROLL];
+};
+
+// main loop of k_dw over rows [r_begin, r_end).  CHECK = false: every row of every stage is in range (no selects
+// between the loads and their use, so the loads of two stages stay in flight behind the MFMAs of the third).
+template <bool CHECK>
+__device__ __forceinline__ void dw_rows(const DwProblem& p, const float* __restrict__ gp, const float* __restrict__ xp, long long r_begin,
+                                        long long r_end, int h, bool do_bias, f32x16 (&acc)[4][DW_CB], float (&bsum)[4]) {
+  auto load = [&](long long r0, DwStage& S) {
+#pragma unroll
+    for (int u = 0; u < DW_UNROLL; ++u) {
+      // both operands have row stride WIDTH floats (all buffers of the workspace do)
+      if (CHECK) {
+        long long r = r0 + 2 * u + h;
+        r = r < r_end ? r : r_end - 1;
+        S.a[u] = *reinterpret_cast<const float4*>(gp + (size_t)r * WIDTH);
+        S.b[u] = *reinterpret_cast<const float2*>(xp + (size_t)r * WIDTH);
+      } else {
+        const size_t off = (size_t)(r0 + h) * WIDTH + (size_t)u * 2 * WIDTH;
+        S.a[u] = *reinterpret_cast<const float4*>(gp + off);
+        S.b[u] = *reinterpret_cast<const float2*>(xp + off);
+      }
+    }
+  };
+  auto mul = [&](long long r0, const DwStage& S) {
+#pragma unroll
+    for (int u = 0; u < DW_UNROLL; ++u) {
+      float4 a = S.a[u];
+      if (CHECK) {
+        if (r0 + 2 * u + h >= r_end) a = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the end contribute nothing
+      }
+#pragma unroll
+      for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < DW_CB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(S.b[u], cb), acc[ca][cb], 0, 0, 0);
+      if (do_bias) {
+        bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w;
+      }
+    }
+  };
+  constexpr long long G = 2 * DW_UNROLL;  // rows per stage
+  DwStage s0, s1, s2;
+  load(r_begin, s0);
+  load(r_begin + G, s1);
+  for (long long r0 = r_begin; r0 < r_end; r0 += 3 * G) {
+    load(r0 + 2 * G, s2);
+    mul(r0, s0);
+    if (CHECK || r0 + 3 * G < r_end) {
+      load(r0 + 3 * G, s0);
+      mul(r0 + G, s1);
+      load(r0 + 4 * G, s1);
+      mul(r0 + 2 * G, s2);
+    } else {  // last trip of the unchecked loop: nothing left to prefetch
+      mul(r0 + G, s1);
+      mul(r0 + 2 * G, s2);
+    }
+  }
+}
+
+// Slab layout per wave block: [cA 4][cB 2][reg 16][lane 64] floats; after the nout*nin block values come nout column sums.
+__global__ __launch_bounds__(512, 2) void k_dw(const DwProblem p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int in_blocks = p.nin / (32 * CB);
-  const int nblocks = (p.nout / 128) * in_blocks;  // 4, 2 or 2
-  const int msubs = 4 / nblocks;
+  const int in_blocks = p.nin / 64;
+  const int nblocks = (p.nout / 128) * in_blocks;  // 8, 4 or 2
+  const int msubs = DW_WAVES / nblocks;
   const int blk = wv % nblocks, msub = wv / nblocks;
-  const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * (32 * CB);
-  // rows of this wave
-  const long long per_wg = ((p.Mtot + DW_WGS - 1) / DW_WGS + (2 * DW_UNROLL * msubs) - 1) / (2 * DW_UNROLL * msubs) * (2 * DW_UNROLL * msubs);
-  const long long per_wave = per_wg / msubs;
+  const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * 64;
+  const long long gran = (long long)2 * DW_UNROLL * DW_STAGES * msubs;
+  const long long per_wg = ((p.Mtot + DW_WGS - 1) / DW_WGS + gran - 1) / gran * gran;
+  const long long per_wave = per_wg / msubs;  // a multiple of the 24 rows of one pipeline round
   const long long r_begin = (long long)blockIdx.x * per_wg + (long long)msub * per_wave;
-  long long r_end = r_begin + per_wave;
-  if (r_end > p.Mtot) r_end = p.Mtot;
+  const long long r_nom = r_begin + per_wave;
+  const long long r_end = r_nom > p.Mtot ? p.Mtot : r_nom;
   const int h = lane >> 5, q = lane & 31;
 
-  f32x16 acc[4][CB];
+  f32x16 acc[4][DW_CB];
 #pragma unroll
   for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int cb = 0; cb < DW_CB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = (p.db != nullptr) && (iB == 0);
 
   const float* gp = p.G + oA + 4 * q;
-  const float* xp = p.X + iB + CB * q;
-  float4 av[DW_UNROLL], an[DW_UNROLL];
-  BV bv[DW_UNROLL], bn[DW_UNROLL];
-
-  auto load = [&](long long r0, float4 (&A)[DW_UNROLL], BV (&Bq)[DW_UNROLL]) {
-#pragma unroll
-    for (int u = 0; u < DW_UNROLL; ++u) {
-      const long long r = r0 + 2 * u + h;
-      const bool ok = r < r_end;
-      const long long rc = ok ? r : (p.Mtot - 1);
-      float4 x = *reinterpret_cast<const float4*>(gp + (size_t)rc * p.ldg);
-      if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
-      A[u] = x;
-      Bq[u] = *reinterpret_cast<const BV*>(xp + (size_t)rc * p.ldx);
-    }
-  };
-
+  const float* xp = p.X + iB + DW_CB * q;
   if (r_begin < r_end) {
-    load(r_begin, av, bv);
-    for (long long r0 = r_begin; r0 < r_end; r0 += 2 * DW_UNROLL) {
-      const long long rn = r0 + 2 * DW_UNROLL;
-      if (rn < r_end) load(rn, an, bn);
-#pragma unroll
-      for (int u = 0; u < DW_UNROLL; ++u) {
-#pragma unroll
-        for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(av[u], ca), comp(bv[u], cb), acc[ca][cb], 0, 0, 0);
-        if (do_bias) {
-          bsum[0] += av[u].x; bsum[1] += av[u].y; bsum[2] += av[u].z; bsum[3] += av[u].w;
-        }
-      }
-      if (rn < r_end) {
-#pragma unroll
-        for (int u = 0; u < DW_UNROLL; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
-      }
-    }
+    if (r_nom <= p.Mtot)
+      dw_rows<false>(p, gp, xp, r_begin, r_end, h, do_bias, acc, bsum);
+    else
+      dw_rows<true>(p, gp, xp, r_begin, r_end, h, do_bias, acc, bsum);
   }
   // write this wave's slab
   const size_t slab_floats = (size_t)p.nout * p.nin + p.nout;
-  const size_t wave_floats = (size_t)4 * CB * 16 * 64;  // = 128 x 32*CB
+  constexpr size_t wave_floats = (size_t)4 * DW_CB * 16 * 64;  // 128 x 64
   float* slab = p.slabs + ((size_t)blockIdx.x * msubs + msub) * slab_floats;
   float* ws = slab + (size_t)blk * wave_floats;
 #pragma unroll
   for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int cb = 0; cb < DW_CB; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ws[((size_t)(ca * CB + cb) * 16 + r) * 64 + lane] = acc[ca][cb][r];
-  if (p.db != nullptr && iB == 0) {
+      for (int r = 0; r < 16; ++r) ws[((size_t)(ca * DW_CB + cb) * 16 + r) * 64 + lane] = acc[ca][cb][r];
+  if (do_bias) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) bsum[c] += __shfl_xor(bsum[c], 32);
     if (h == 0) {
@@ -335,13 +362,21 @@ __global__ __launch_bounds__(256, 1) void k_dw(const DwProblem p) {
 }
 
 // sums the slabs and scatters into the nn.Linear-layout gradient
-__global__ __launch_bounds__(256) void k_dw_reduce(const DwProblem p, int CB, int nslabs) {
+__global__ __launch_bounds__(256) void k_dw_reduce(const DwProblem p, int nslabs) {
+  constexpr int CB = DW_CB;
   const int total = p.nout * p.nin + (p.db ? p.nout : 0);
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const size_t slab_floats = (size_t)p.nout * p.nin + p.nout;
-  float s = 0.f;
-  for (int k = 0; k < nslabs; ++k) s += p.slabs[(size_t)k * slab_floats + e];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // nslabs is a multiple of 8: eight independent loads in flight
+  for (int k = 0; k < nslabs; k += 8) {
+    const float* q = p.slabs + (size_t)k * slab_floats + e;
+    const float v0 = q[0], v1 = q[slab_floats], v2 = q[2 * slab_floats], v3 = q[3 * slab_floats];
+    const float v4 = q[4 * slab_floats], v5 = q[5 * slab_floats], v6 = q[6 * slab_floats], v7 = q[7 * slab_floats];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+  }
+  const float s = (s0 + s1) + (s2 + s3);
   if (e < p.nout * p.nin) {
     const int wave_floats = 4 * CB * 16 * 64;
     const int in_blocks = p.nin / (32 * CB);
@@ -365,7 +400,7 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwProblem p, int CB, in
 // ------------------------------------------------------------------------------------------------
 // colour head (dW_c[3][128], db_c[3]) and sigma head (dw_sigma[256], db_sigma): plain VALU column reductions with
 // one float atomic per (workgroup, output).  Destinations must be zeroed beforehand.
-constexpr int SG_WGS = 1024;
+constexpr int SG_WGS = 4096;
 __global__ __launch_bounds__(256) void k_small_heads(const SmallGradArgs a) {
   const int t = threadIdx.x;
   const long long per = (a.Mtot + SG_WGS - 1) / SG_WGS;
@@ -419,12 +454,20 @@ __global__ __launch_bounds__(128) void k_dir_ray_sums(const SmallGradArgs a) {
     a.gdbuf[(size_t)ray * DIR_DIM + c * 8 + 2 * l + 1] = cosf(ph);
   }
 }
+constexpr int DG_CHUNKS = 64;
+__global__ __launch_bounds__(128) void k_dir_gamma_zero(const SmallGradArgs a) {
+  const int o = threadIdx.x;
+  for (int k = 0; k < DIR_DIM; ++k) a.dW_dir[(size_t)o * (WIDTH + DIR_DIM) + k] = 0.f;
+}
 __global__ __launch_bounds__(128) void k_dir_gamma_dw(const SmallGradArgs a) {
-  // block k (0..23), thread o (0..127)
+  // block (k, chunk of rays), thread o (0..127); one float atomic per (block, o)
   const int k = blockIdx.x, o = threadIdx.x;
+  const int per = (a.B + DG_CHUNKS - 1) / DG_CHUNKS;
+  const int r0 = blockIdx.y * per;
+  const int r1 = (r0 + per) < a.B ? (r0 + per) : a.B;
   float s = 0.f;
-  for (int ray = 0; ray < a.B; ++ray) s = __builtin_fmaf(a.sbuf[(size_t)ray * HALF + o], a.gdbuf[(size_t)ray * DIR_DIM + k], s);
-  a.dW_dir[(size_t)o * (WIDTH + DIR_DIM) + k] = s;
+  for (int ray = r0; ray < r1; ++ray) s = __builtin_fmaf(a.sbuf[(size_t)ray * HALF + o], a.gdbuf[(size_t)ray * DIR_DIM + k], s);
+  if (r0 < r1) atomicAdd(a.dW_dir + (size_t)o * (WIDTH + DIR_DIM) + k, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -447,29 +490,30 @@ hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st) {
 }
 
 size_t dw_slab_floats(int nout, int nin) {
-  // up to 2 sub-chunks per workgroup
-  return (size_t)DW_WGS * 2 * ((size_t)nout * nin + nout);
+  const int nblocks = (nout / 128) * (nin / 64);
+  return (size_t)DW_WGS * (DW_WAVES / nblocks) * ((size_t)nout * nin + nout);
+}
+size_t dw_slab_floats_max() {
+  size_t a = dw_slab_floats(256, 256), b = dw_slab_floats(128, 256), c = dw_slab_floats(256, 64);
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 hipError_t launch_dw(const DwProblem& p, hipStream_t st) {
-  const int CB = (p.nin >= 128) ? 4 : 2;
-  const int nblocks = (p.nout / 128) * (p.nin / (32 * CB));
-  const int msubs = 4 / nblocks;
-  if (CB == 4)
-    hipLaunchKernelGGL(k_dw<4>, dim3(DW_WGS), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL(k_dw<2>, dim3(DW_WGS), dim3(256), 0, st, p);
+  const int nblocks = (p.nout / 128) * (p.nin / 64);
+  const int msubs = DW_WAVES / nblocks;
+  hipLaunchKernelGGL(k_dw, dim3(DW_WGS), dim3(512), 0, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int total = p.nout * p.nin + (p.db ? p.nout : 0);
-  hipLaunchKernelGGL(k_dw_reduce, dim3((total + 255) / 256), dim3(256), 0, st, p, CB, DW_WGS * msubs);
+  hipLaunchKernelGGL(k_dw_reduce, dim3((total + 255) / 256), dim3(256), 0, st, p, DW_WGS * msubs);
   return hipGetLastError();
 }
 
 hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_small_heads, dim3(SG_WGS), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_dir_ray_sums, dim3(a.B), dim3(128), 0, st, a);
-  hipLaunchKernelGGL(k_dir_gamma_dw, dim3(DIR_DIM), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(k_dir_gamma_zero, dim3(1), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(k_dir_gamma_dw, dim3(DIR_DIM, DG_CHUNKS), dim3(128), 0, st, a);
   return hipGetLastError();
 }
 

@@ -158,6 +158,7 @@ struct SmallGradArgs {
 hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st);
 hipError_t launch_dw(const DwProblem& p, hipStream_t st);
 size_t dw_slab_floats(int nout, int nin);
+size_t dw_slab_floats_max();
 hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st);
 size_t merge_bwd_lds_bytes(int N);
 hipError_t launch_merge_bwd(const MergeBwdArgs& a, hipStream_t st);

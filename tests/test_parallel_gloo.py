@@ -1,0 +1,86 @@
+"""CPU, world_size 2 over gloo: the host-side logic of the multi-GPU path (sharding, the flat SUM bucket, assembling
+shards).  The kernels themselves need a GPU; their shard-sum property is checked on one GPU in
+tests/test_gpu_backward.py::test_sum_of_shard_gradients_equals_full_batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nerf_tiny_amd as P
+        from nerf_tiny_amd import parallel as par
+
+        torch.manual_seed(0)
+        m = P.NeRFModel(64, 128, 8)
+        params = list(m.network.parameters())
+        # per-rank "gradients": rank r contributes (r + 1) * g
+        gen = torch.Generator().manual_seed(1)
+        base = [torch.randn(p.shape, generator=gen) for p in params]
+        for p, g in zip(params, base):
+            p.grad = (rank + 1) * g.clone()
+        b = par.GradBucket(params)
+        assert b.flat.numel() == 593924
+        b.allreduce_sum()
+        tot = sum(range(1, world + 1))
+        ok = all(torch.allclose(p.grad, tot * g, rtol=1e-6, atol=1e-7) for p, g in zip(params, base))
+        # shards cover [0, n) exactly, in order
+        n = 1003
+        bounds = [par.shard_bounds(n, r, world) for r in range(world)]
+        ok &= bounds[0][0] == 0 and bounds[-1][1] == n and all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+        lo, hi = bounds[rank]
+        full = torch.arange(n * 3, dtype=torch.float32).view(n, 3)
+        got = par.gather_rows(full[lo:hi].clone(), n, rank, world)
+        ok &= torch.equal(got, full)
+        pb = torch.zeros(4, 17, dtype=torch.float64)
+        pb[0, 15], pb[0, 16] = 2.1, 6.3
+        ok &= par.global_ray0(pb) == (float(torch.tensor(2.1, dtype=torch.float32)), float(torch.tensor(6.3, dtype=torch.float32)))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucket_and_sharding_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_bounds_properties():
+    from nerf_tiny_amd import parallel as par
+
+    for n in (0, 1, 7, 4096, 640000, 762048):
+        for world in (1, 2, 3, 8):
+            b = [par.shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            sizes = [h - l for l, h in b]
+            assert max(sizes) - min(sizes) <= 1
