@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_hip.so")
+LIB_PATH = os.environ.get("NERF_HIP_LIB", os.path.join(_HERE, "libnerf_hip.so"))  # override: diagnostic builds only
 
 NERF_HIP_ABI_VERSION = 1
 SAVE_FOR_BACKWARD = 1 << 0

@@ -194,6 +194,9 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.rgb = at<float>(ws, L.rgb_c);
   fa.sigma = at<float>(ws, L.sig_c);
   fa.N = Nc; fa.M = B * Nc;
+#ifdef NERF_STAMPS
+  fa.stamps = at<unsigned long long>(ws, L.status) + 8;  // diagnostic build: cycle sums live behind the status word
+#endif
   const int tiles_c = (B * Nc + TM - 1) / TM, tiles_f = (B * Nf + TM - 1) / TM;
   if (save) {
     fa.save = at<float>(ws, L.save); fa.masks = at<uint16_t>(ws, L.masks); fa.spre = at<float>(ws, L.spre);

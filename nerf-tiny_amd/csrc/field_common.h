@@ -10,47 +10,96 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // building blocks of the fused kernels
 // ------------------------------------------------------------------------------------------
 
-// acc[f][st] += W[ft0+f tile][k] * act[st*32 + sample][k]  for k in [0, 8*KB)
+// A fragments of k-blocks 0 and 1 of a packed segment for this wave's NFT feature tiles; issued EARLY (before the
+// barriers / epilogue of the previous layer) so that the L2 latency of a layer's first loads hides behind them
+template <int NFT> struct WFrag { float4 c[NFT]; float4 n[NFT]; };
+
+template <int KB, int NFT>
+__device__ __forceinline__ void wfrag_first(const float4* __restrict__ wseg, int ft0, int lane, WFrag<NFT>& w) {
+  const float4* wbase = wseg + (size_t)ft0 * KB * 64 + lane;
+#pragma unroll
+  for (int f = 0; f < NFT; ++f) w.c[f] = wbase[(size_t)f * KB * 64];
+#pragma unroll
+  for (int f = 0; f < NFT; ++f) w.n[f] = wbase[(size_t)(f * KB + 1) * 64];
+}
+
+// acc[f][st] += W[ft0+f tile][k] * act[st*32 + sample][k]  for k in [0, 8*KB); w = fragments of k-blocks 0, 1 (wfrag_first).
+// The A fragments of k-block kb+2 are requested before the MFMAs of k-block kb (two k-blocks = 2048+ cycles of MFMA
+// cover the L2 latency also when the partner wave on the SIMD is stalled).
 template <int KB, int NFT>
 __device__ __forceinline__ void mfma_layer(const float4* __restrict__ wseg, int ft0, const float* act, int kcol0, int lane,
-                                           f32x16 (&acc)[NFT][2]) {
+                                           f32x16 (&acc)[NFT][2], WFrag<NFT>& w) {
   const int j = lane & 31, h = lane >> 5;
   const float* a0p = act + j * LDA + kcol0 + 4 * h;
   const float* a1p = a0p + 32 * LDA;
   const float4* wbase = wseg + (size_t)ft0 * KB * 64 + lane;
-  float4 wc[NFT], wn[NFT];
-#pragma unroll
-  for (int f = 0; f < NFT; ++f) wc[f] = wbase[(size_t)f * KB * 64];
+  float4 w2[NFT];
 #pragma unroll 2
   for (int kb = 0; kb < KB; ++kb) {
-    const int kn = (kb + 1 < KB) ? kb + 1 : kb;
+    const int k2 = (kb + 2 < KB) ? kb + 2 : KB - 1;
 #pragma unroll
-    for (int f = 0; f < NFT; ++f) wn[f] = wbase[(size_t)(f * KB + kn) * 64];
+    for (int f = 0; f < NFT; ++f) w2[f] = wbase[(size_t)(f * KB + k2) * 64];
     const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
     const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
 #pragma unroll
     for (int f = 0; f < NFT; ++f) {
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].x, a0.x, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].x, a1.x, acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.c[f].x, a0.x, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.c[f].x, a1.x, acc[f][1], 0, 0, 0);
     }
 #pragma unroll
     for (int f = 0; f < NFT; ++f) {
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].y, a0.y, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].y, a1.y, acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.c[f].y, a0.y, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.c[f].y, a1.y, acc[f][1], 0, 0, 0);
     }
 #pragma unroll
     for (int f = 0; f < NFT; ++f) {
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].z, a0.z, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].z, a1.z, acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.c[f].z, a0.z, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.c[f].z, a1.z, acc[f][1], 0, 0, 0);
     }
 #pragma unroll
     for (int f = 0; f < NFT; ++f) {
-      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].w, a0.w, acc[f][0], 0, 0, 0);
-      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[f].w, a1.w, acc[f][1], 0, 0, 0);
+      acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.c[f].w, a0.w, acc[f][0], 0, 0, 0);
+      acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.c[f].w, a1.w, acc[f][1], 0, 0, 0);
     }
 #pragma unroll
-    for (int f = 0; f < NFT; ++f) wc[f] = wn[f];
+    for (int f = 0; f < NFT; ++f) {
+      w.c[f] = w.n[f];
+      w.n[f] = w2[f];
+    }
   }
+}
+
+// convenience form: loads its own first fragments
+template <int KB, int NFT>
+__device__ __forceinline__ void mfma_layer(const float4* __restrict__ wseg, int ft0, const float* act, int kcol0, int lane,
+                                           f32x16 (&acc)[NFT][2]) {
+  WFrag<NFT> w;
+  wfrag_first<KB, NFT>(wseg, ft0, lane, w);
+  mfma_layer<KB, NFT>(wseg, ft0, act, kcol0, lane, acc, w);
+}
+
+// bias values of this lane's accumulator rows, requested EARLY (like wfrag_first) and applied by acc_init_regs
+template <int NFT>
+__device__ __forceinline__ void bias_first(const float* __restrict__ bias, int fbase, int lane, float4 (&bq)[NFT][4]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int f = 0; f < NFT; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[f][g] = *reinterpret_cast<const float4*>(bias + fbase + f * 32 + 8 * g + 4 * h);
+}
+template <int NFT>
+__device__ __forceinline__ void acc_init_regs(const float4 (&bq)[NFT][4], f32x16 (&acc)[NFT][2]) {
+#pragma unroll
+  for (int f = 0; f < NFT; ++f)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        acc[f][st][4 * g + 0] = bq[f][g].x;
+        acc[f][st][4 * g + 1] = bq[f][g].y;
+        acc[f][st][4 * g + 2] = bq[f][g].z;
+        acc[f][st][4 * g + 3] = bq[f][g].w;
+      }
 }
 
 // accumulators <- bias (feature = fbase + f*32 + 8g + 4h + r for register 4g + r)

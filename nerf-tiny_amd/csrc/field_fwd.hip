@@ -91,8 +91,25 @@ __global__ void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg) 
 // ------------------------------------------------------------------------------------------
 // the fused forward kernel
 // ------------------------------------------------------------------------------------------
+#ifdef NERF_STAMPS
+#define STAMP(slot)                                                   \
+  do {                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    const unsigned long long t_ = __builtin_readcyclecounter();       \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    tsum[slot] += t_ - tlast;                                         \
+    tlast = t_;                                                       \
+  } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 template <bool SAVE>
 __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
+#ifdef NERF_STAMPS
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* act = smem;
   float* scr = smem + TM * LDA;  // [4][64][3]
@@ -111,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   uint16_t* mk = SAVE ? a.masks + ((size_t)(a.tile0 + blockIdx.x) * 4) * 256 + tid : nullptr;
   const size_t MKS = (size_t)a.tiles_tot * 4 * 256;      // stride between mask layers
 
+  __builtin_amdgcn_s_setprio(2);
   float p[3];
   sample_point(rf, a.t[mc], p);
   if (a.pts_dbg && valid && wv == 0) {
@@ -119,7 +137,9 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
     a.pts_dbg[(size_t)m * 3 + 2] = p[2];
   }
   encode_point_to_lds(p, act, sm, wv);
+  STAMP(0);
   __syncthreads();
+  STAMP(4);
   if (a.gp_dbg) {
     for (int idx = tid; idx < TM * POINT_DIM; idx += 256) {
       const int r = idx / POINT_DIM, c = idx - r * POINT_DIM;
@@ -132,45 +152,87 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   f32x16 acc[2][2];
   const int fbase = wv * 64;
 
+  // Each layer's first weight fragments are requested before the previous layer's barriers and epilogue.
+  WFrag<2> wc;
+  float4 bq[2][4];
   // ---- layer 0: 60(64) -> 256
   acc_init_bias<2>(a.w.p[B_L0], fbase, lane, acc);
+  __builtin_amdgcn_s_setprio(0);
   mfma_layer<8, 2>(a.wp + seg_off4(SEG_L0), wv * 2, act, 0, lane, acc);
+  __builtin_amdgcn_s_setprio(2);  // VALU/LDS phases outrank the partner workgroup's MFMA stream
+  STAMP(1);
+  wfrag_first<32, 2>(a.wp + seg_off4(SEG_L1), wv * 2, lane, wc);
+  bias_first<2>(a.w.p[3], fbase, lane, bq);
   __syncthreads();
+  STAMP(2);
   acc_store<2, true>(act, fbase, lane, acc, mk);
+  STAMP(3);
   __syncthreads();
+  STAMP(4);
   if (SAVE) save_rows(act, a.save + 0 * MS, grow0, nrows, 64, WIDTH, tid);
 
   // ---- layers 1..3
 #pragma unroll 1
   for (int l = 1; l <= 3; ++l) {
-    acc_init_bias<2>(a.w.p[2 * l + 1], fbase, lane, acc);
-    mfma_layer<32, 2>(a.wp + seg_off4(SEG_L1) + (size_t)(l - 1) * 8 * 32 * 64, wv * 2, act, 0, lane, acc);
+    acc_init_regs<2>(bq, acc);
+    __builtin_amdgcn_s_setprio(0);
+    mfma_layer<32, 2>(a.wp + seg_off4(SEG_L1) + (size_t)(l - 1) * 8 * 32 * 64, wv * 2, act, 0, lane, acc, wc);
+    __builtin_amdgcn_s_setprio(2);  // VALU/LDS phases outrank the partner workgroup's MFMA stream
+  STAMP(1);
+    // next: layer l+1 (L2, L3) or L4A -- consecutive segments of equal size
+    wfrag_first<32, 2>(a.wp + seg_off4(SEG_L1) + (size_t)l * 8 * 32 * 64, wv * 2, lane, wc);
+    bias_first<2>(a.w.p[2 * (l + 1) + 1], fbase, lane, bq);
     __syncthreads();
+  STAMP(2);
     acc_store<2, true>(act, fbase, lane, acc, SAVE ? mk + l * MKS : nullptr);
+  STAMP(3);
     __syncthreads();
+  STAMP(4);
     if (SAVE) save_rows(act, a.save + (size_t)l * MS, grow0, nrows, 64, WIDTH, tid);
   }
 
   // ---- layer 4: cat(h3, gamma_p) (hidden first, nerf.py:109) -> 256
-  acc_init_bias<2>(a.w.p[9], fbase, lane, acc);
-  mfma_layer<32, 2>(a.wp + seg_off4(SEG_L4A), wv * 2, act, 0, lane, acc);
+  acc_init_regs<2>(bq, acc);
+  __builtin_amdgcn_s_setprio(0);
+  mfma_layer<32, 2>(a.wp + seg_off4(SEG_L4A), wv * 2, act, 0, lane, acc, wc);
+  __builtin_amdgcn_s_setprio(2);  // VALU/LDS phases outrank the partner workgroup's MFMA stream
+  STAMP(1);
+  wfrag_first<8, 2>(a.wp + seg_off4(SEG_L4B), wv * 2, lane, wc);
   __syncthreads();
+  STAMP(2);
   encode_point_to_lds(p, act, sm, wv);  // re-encode into the (now free) activation buffer
   __syncthreads();
-  mfma_layer<8, 2>(a.wp + seg_off4(SEG_L4B), wv * 2, act, 0, lane, acc);
+  __builtin_amdgcn_s_setprio(0);
+  mfma_layer<8, 2>(a.wp + seg_off4(SEG_L4B), wv * 2, act, 0, lane, acc, wc);
+  __builtin_amdgcn_s_setprio(2);  // VALU/LDS phases outrank the partner workgroup's MFMA stream
+  STAMP(1);
+  wfrag_first<32, 2>(a.wp + seg_off4(SEG_L5), wv * 2, lane, wc);
+  bias_first<2>(a.w.p[11], fbase, lane, bq);
   __syncthreads();
+  STAMP(2);
   acc_store<2, true>(act, fbase, lane, acc, SAVE ? mk + 4 * MKS : nullptr);
+  STAMP(3);
   __syncthreads();
+  STAMP(4);
   if (SAVE) save_rows(act, a.save + 4 * MS, grow0, nrows, 64, WIDTH, tid);
 
   // ---- layers 5..7
 #pragma unroll 1
   for (int l = 5; l <= 7; ++l) {
-    acc_init_bias<2>(a.w.p[2 * l + 1], fbase, lane, acc);
-    mfma_layer<32, 2>(a.wp + seg_off4(SEG_L5) + (size_t)(l - 5) * 8 * 32 * 64, wv * 2, act, 0, lane, acc);
+    acc_init_regs<2>(bq, acc);
+    __builtin_amdgcn_s_setprio(0);
+    mfma_layer<32, 2>(a.wp + seg_off4(SEG_L5) + (size_t)(l - 5) * 8 * 32 * 64, wv * 2, act, 0, lane, acc, wc);
+    __builtin_amdgcn_s_setprio(2);  // VALU/LDS phases outrank the partner workgroup's MFMA stream
+  STAMP(1);
+    // next: L6, L7 or point_info -- consecutive segments of equal size
+    wfrag_first<32, 2>(a.wp + seg_off4(SEG_L5) + (size_t)(l - 4) * 8 * 32 * 64, wv * 2, lane, wc);
+    bias_first<2>(l < 7 ? a.w.p[2 * (l + 1) + 1] : a.w.p[B_PI], fbase, lane, bq);
     __syncthreads();
+  STAMP(2);
     acc_store<2, true>(act, fbase, lane, acc, SAVE ? mk + l * MKS : nullptr);
+  STAMP(3);
     __syncthreads();
+  STAMP(4);
     if (SAVE) save_rows(act, a.save + (size_t)l * MS, grow0, nrows, 64, WIDTH, tid);
   }
 
@@ -191,20 +253,15 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   }
 
   // ---- point_info: 256 -> 256, no activation (nerf.py:96, 117)
-  acc_init_bias<2>(a.w.p[B_PI], fbase, lane, acc);
-  mfma_layer<32, 2>(a.wp + seg_off4(SEG_PI), wv * 2, act, 0, lane, acc);
-  __syncthreads();
-  if (wv == 0 && valid) {
-    const float pre = ((scr[sm] + scr[64 + sm]) + (scr[128 + sm] + scr[192 + sm])) + a.w.p[B_SIGMA][0];
-    a.sigma[m] = fabsf(pre);
-    if (SAVE) a.spre[a.row0 + m] = pre;
-  }
-  acc_store<2, false>(act, fbase, lane, acc);
-  __syncthreads();
-  if (SAVE) save_rows(act, a.save + S_FEAT * MS, grow0, nrows, 64, WIDTH, tid);
-
-  // ---- dir_info: cat(gamma_d, feat) -> 128, ReLU (nerf.py:98, 118).  The gamma_d part (+ bias) is per ray: dvec.
-  f32x16 acd[1][2];
+  acc_init_regs<2>(bq, acc);
+  __builtin_amdgcn_s_setprio(0);
+  mfma_layer<32, 2>(a.wp + seg_off4(SEG_PI), wv * 2, act, 0, lane, acc, wc);
+  __builtin_amdgcn_s_setprio(2);  // VALU/LDS phases outrank the partner workgroup's MFMA stream
+  STAMP(1);
+  WFrag<1> wd;
+  wfrag_first<32, 1>(a.wp + seg_off4(SEG_DIR), wv, lane, wd);
+  // dir_info: the gamma_d part (+ bias) of the pre-activation is per ray (dvec); requested before the barrier as well
+  float4 dq[2][4];
   {
     const int j = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -213,19 +270,43 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
       ms = ms < a.M ? ms : a.M - 1;
       const float* dv = a.dvec + (size_t)(ms / a.N) * HALF + wv * 32 + 4 * h;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b = *reinterpret_cast<const float4*>(dv + 8 * g);
-        acd[0][st][4 * g + 0] = b.x;
-        acd[0][st][4 * g + 1] = b.y;
-        acd[0][st][4 * g + 2] = b.z;
-        acd[0][st][4 * g + 3] = b.w;
-      }
+      for (int g = 0; g < 4; ++g) dq[st][g] = *reinterpret_cast<const float4*>(dv + 8 * g);
     }
   }
-  mfma_layer<32, 1>(a.wp + seg_off4(SEG_DIR), wv, act, 0, lane, acd);
   __syncthreads();
+  STAMP(2);
+  if (wv == 0 && valid) {
+    const float pre = ((scr[sm] + scr[64 + sm]) + (scr[128 + sm] + scr[192 + sm])) + a.w.p[B_SIGMA][0];
+    a.sigma[m] = fabsf(pre);
+    if (SAVE) a.spre[a.row0 + m] = pre;
+  }
+  acc_store<2, false>(act, fbase, lane, acc);
+  STAMP(3);
+  __syncthreads();
+  STAMP(4);
+  if (SAVE) save_rows(act, a.save + S_FEAT * MS, grow0, nrows, 64, WIDTH, tid);
+
+  // ---- dir_info: cat(gamma_d, feat) -> 128, ReLU (nerf.py:98, 118)
+  f32x16 acd[1][2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acd[0][st][4 * g + 0] = dq[st][g].x;
+      acd[0][st][4 * g + 1] = dq[st][g].y;
+      acd[0][st][4 * g + 2] = dq[st][g].z;
+      acd[0][st][4 * g + 3] = dq[st][g].w;
+    }
+  __builtin_amdgcn_s_setprio(0);
+  mfma_layer<32, 1>(a.wp + seg_off4(SEG_DIR), wv, act, 0, lane, acd, wd);
+  __builtin_amdgcn_s_setprio(2);  // VALU/LDS phases outrank the partner workgroup's MFMA stream
+  STAMP(1);
+  __syncthreads();
+  STAMP(2);
   acc_store<1, true>(act, wv * 32, lane, acd);
+  STAMP(3);
   __syncthreads();
+  STAMP(4);
   if (SAVE) save_rows(act, a.save + S_C * MS, grow0, nrows, 32, WIDTH, tid);
 
   // ---- colour head (VALU): rgb = sigmoid(W_c c + b)   (nerf.py:99, 119)
@@ -261,6 +342,13 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
       a.rgb[(size_t)(m0 + s) * 3 + ch] = 1.0f / (1.0f + expf(-z));
     }
   }
+#ifdef NERF_STAMPS
+  STAMP(5);
+  if (a.stamps && lane == 0 && wv == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, tsum[i]);
+    atomicAdd(a.stamps + 7, 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -272,7 +360,8 @@ hipError_t launch_pack_weights(const Weights24& w, float4* out, int nseg, hipStr
   return hipGetLastError();
 }
 
-hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st) {
+hipError_t launch_field_fwd(const FieldArgs& a_in, bool save, hipStream_t st) {
+  const FieldArgs& a = a_in;
   const int tiles = (a.M + TM - 1) / TM;
   const size_t lds = FIELD_LDS_FLOATS * sizeof(float);
   static bool attr_set = false;

@@ -27,6 +27,7 @@ struct FieldArgs {
   long long Mtot;
   int N;                   // samples per ray
   int M;                   // samples of this pass (B*N)
+  unsigned long long* stamps;  // diagnostic build (-DNERF_STAMPS) only: [8] cycle sums per phase
 };
 
 constexpr int S_H0 = 0, S_FEAT = 8, S_C = 9, S_GP = 10, NSAVE = 11;

@@ -1,0 +1,26 @@
+"""Diagnostic: where a k_field_fwd workgroup spends its cycles (needs `make -C nerf-tiny_amd/csrc stamps`;
+run with NERF_HIP_LIB=nerf-tiny_amd/libnerf_hip_stamps.so).  Shares only -- a stamped build is slower."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+import nerf_tiny_amd as P
+from nerf_tiny_amd import _abi
+dev = torch.device("cuda:0")
+row, col, pb, K, Ct = bench.synth_inputs(1000)
+m = bench.synth_weights(0).to(dev)
+row, col, pb = row.to(dev), col.to(dev), pb.float().to(dev)
+with torch.no_grad():
+    m(row, col, pb, K)
+    ws = next(iter(m._ws.values()))
+    st = ws[:256].view(torch.int64)
+    st[8:16] = 0
+    m(row, col, pb, K)
+    torch.cuda.synchronize()
+    v = st[8:16].cpu().tolist()
+names = ["encode/prologue", "mfma loops", "barrier after mfma", "acc_store", "barrier after store", "heads+rest"]
+n = v[7]; tot = sum(v[:6])
+print("workgroups", n, "cycles/WG (wave 0)", tot / n)
+for nm, x in zip(names, v[:6]):
+    print(f"  {nm:22s} {x / n:10.0f} cycles  {100 * x / tot:5.1f} %")
