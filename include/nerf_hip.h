@@ -50,6 +50,8 @@ enum {
 /* flags */
 enum {
   NERF_HIP_SAVE_FOR_BACKWARD = 1 << 0, /* forward keeps activations in the workspace for nerf_hip_backward */
+  NERF_HIP_FORCE_TILE_KERNEL = 1 << 1, /* inference: use the LDS-tile field kernel instead of the register-resident one
+                                          (same results up to summation order; for A/B measurements and tests) */
 };
 
 /* status word bits (nerf_hip_read_status) */

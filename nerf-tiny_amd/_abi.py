@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB", os.path.join(_HERE, "libnerf_hip.so"))
 
 NERF_HIP_ABI_VERSION = 1
 SAVE_FOR_BACKWARD = 1 << 0
+FORCE_TILE_KERNEL = 1 << 1
 STATUS_RESAMPLE_INDEX = 1 << 0
 
 _p = C.c_void_p

@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
         const float ph = x * fl;
         const float2 dg = *reinterpret_cast<const float2*>(act + sm * LDA + c * 20 + 2 * l);
         // d/dx [sin(f x), cos(f x)] . dgamma = f (cos * dg_sin - sin * dg_cos)
-        const float dph = cosf(ph) * dg.x - sinf(ph) * dg.y;
+        float sn, cn;
+        sincos_phase(ph, sn, cn);
+        const float dph = cn * dg.x - sn * dg.y;
         const float contrib = fl * dph;
         if (c == 0) dp[0] += contrib; else if (c == 1) dp[1] += contrib; else dp[2] += contrib;
       }

@@ -158,6 +158,28 @@ __device__ __forceinline__ void sample_point(const float* __restrict__ rf, float
   for (int c = 0; c < 3; ++c) p[c] = ((rf[RF_R + 3 * c] * v0 + rf[RF_R + 3 * c + 1] * v1) + rf[RF_R + 3 * c + 2] * v2) + rf[RF_O + c];
 }
 
+// sin and cos of a phase of magnitude up to ~1e6 rad, each within 1 ulp of the correctly rounded value on [-1, 1]:
+// the argument is reduced in fp64 (r = ph - n*pi/2 with one fma: error < 1e-10 rad for |ph| < 2^20), then the cephes
+// single-precision minimax polynomials on [-pi/4, pi/4] are evaluated in fp32 and the quadrant is applied.
+// ~25 instructions instead of the ~150 (plus a Payne-Hanek loop) of the generic sinf + cosf pair.
+__device__ __forceinline__ void sincos_phase(float ph, float& sn, float& cs) {
+  const double x = (double)ph;
+  const double n = __builtin_rint(x * 0.63661977236758134308);           // 2/pi
+  const float r = (float)__builtin_fma(-n, 1.57079632679489661923, x);  // pi/2
+  const int q = (int)n;
+  const float z = r * r;
+  float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+  ps = __builtin_fmaf(ps * z, r, r);  // sin(r)
+  float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+  pc = __builtin_fmaf(pc * z, z, __builtin_fmaf(z, -0.5f, 1.0f));  // cos(r)
+  const float a = (q & 1) ? pc : ps;
+  const float b = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
 // gamma_p of this thread's sample -> act[sm][0..63] (cols 60..63 = 0).  Wave wv writes (c,l) pairs 8wv .. 8wv+7.
 // gamma[c*20 + 2l + s] = (sin, cos)[s](fp32(x_c * f_l))   (nerf.py:135-167, flatten nerf.py:103)
 __device__ __forceinline__ void encode_point_to_lds(const float (&p)[3], float* act, int sm, int wv) {
@@ -170,8 +192,7 @@ __device__ __forceinline__ void encode_point_to_lds(const float (&p)[3], float* 
       const int c = e / 10, l = e - 10 * c;
       const float x = (c == 0) ? p[0] : ((c == 1) ? p[1] : p[2]);
       const float ph = x * __uint_as_float(kFreqPointBits[l]);
-      sc.x = sinf(ph);
-      sc.y = cosf(ph);
+      sincos_phase(ph, sc.x, sc.y);
       col = c * 20 + 2 * l;
     } else {
       col = 60 + 2 * (e - 30);

@@ -1,0 +1,254 @@
+// field_fwd_reg.hip -- inference forward of the field query with REGISTER-RESIDENT activations (MI355X / gfx950).
+//
+// Same arithmetic as k_field_fwd (field_fwd.hip) and the same packed weight image, but no LDS and no barriers:
+//   * one 64-lane wave owns 32 samples and computes ALL 256 features of every layer for them:
+//     D[feature][sample] = W . act  with v_mfma_f32_32x32x2_f32, 8 feature tiles x 16 accumulator VGPRs;
+//   * in the 32x32 accumulator layout lane (j, h) holds features 32t + 8g + 4h + r of sample j.  The MFMA sums over
+//     its two lane halves, and WHICH k each half supplies is free as long as A and B agree -- so the post-ReLU
+//     accumulator registers of layer L are used, as they stand, as the B operand of layer L+1
+//     (k-step (t, 4g + r): half h supplies k = 32t + 8g + 4h + r), and the A fragment that goes with it is the
+//     4 consecutive weights W[i][32t + 8g + 4h .. +3] -- exactly the float4 the packed image already stores;
+//   * nothing is shared between waves, so nothing synchronises: a wave streams 9,242 MFMAs per tile with a
+//     2-stage register pipeline of A fragments (8 x 16-byte loads per k-block, L2/L1 resident, requested one
+//     k-block = 32 MFMAs = 2048 cycles ahead, also across layer boundaries);
+//   * biases enter as one extra MFMA per tile (A = bias, B = 1 on lane half 0); the sigma and colour heads are
+//     VALU dot products over the registers the wave already holds.
+// One wave per SIMD (about 400 VGPRs).  Used when nothing has to be saved for backward.
+#include "field_common.h"
+
+namespace nerf {
+
+constexpr int RM = 32;  // samples per wave
+
+template <int NFT>
+struct WStage {
+  float4 w[NFT];
+};
+
+template <int KB, int NFT>
+__device__ __forceinline__ void stage_load(const float4* __restrict__ seg_lane, int kb, WStage<NFT>& s) {
+#pragma unroll
+  for (int f = 0; f < NFT; ++f) s.w[f] = seg_lane[(size_t)(f * KB + kb) * 64];
+}
+
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// acc[f] (+)= sum_k W[f-tile][k] * in[k]   over KB k-blocks of 8; in = KB/4 register tiles in accumulator layout.
+// Two fragment stages: the A fragments of k-block kb+1 (or k-block 0 of the NEXT segment: NKB k-blocks, NNFT tiles) are
+// requested at the top of k-block kb, i.e. 32 MFMAs = 2048 cycles before their first use; the scheduling barrier keeps
+// the compiler from sinking the requests towards their uses.  st0 holds k-block 0 on entry and the next segment's
+// k-block 0 on exit.
+template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT>
+__device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
+                                          const f32x16* in, f32x16 (&acc)[8], WStage<8>& st0) {
+  const float4* sl = seg + lane;
+  const float4* nl = next_seg + lane;
+  WStage<8> st1;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    WStage<8>& ld = (kb & 1) ? st0 : st1;
+    const WStage<8>& cur = (kb & 1) ? st1 : st0;
+    if (kb + 1 < KB) {
+#pragma unroll
+      for (int f = 0; f < NFT; ++f) ld.w[f] = sl[(size_t)(f * KB + kb + 1) * 64];
+    } else if (next_seg != nullptr) {
+#pragma unroll
+      for (int f = 0; f < NNFT; ++f) ld.w[f] = nl[(size_t)(f * NKB) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float b = in[kb >> 2][4 * (kb & 3) + s];
+#pragma unroll
+      for (int f = 0; f < NFT; ++f) {
+        if (ZERO_INIT && kb == 0 && s == 0)
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(cur.w[f], s), b, zero, 0, 0, 0);
+        else
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(cur.w[f], s), b, acc[f], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (KB & 1) st0 = st1;  // (all segments have an even number of k-blocks: the next k-block 0 already sits in st0)
+}
+
+// bias rows of this lane (requested before the layer's k loop, consumed after it)
+template <int NFT>
+__device__ __forceinline__ void bias_load(const float* __restrict__ bias, int lane, float (&bv)[8]) {
+#pragma unroll
+  for (int f = 0; f < NFT; ++f) bv[f] = bias[f * 32 + (lane & 31)];
+}
+// acc[f] += bias[f*32 + i] (one MFMA per tile: A = bias on every lane, B = 1 on lane half 0, 0 on half 1)
+template <int NFT>
+__device__ __forceinline__ void add_bias(const float (&bv)[8], int lane, f32x16 (&acc)[8]) {
+  const float one_h0 = (lane < 32) ? 1.0f : 0.0f;
+#pragma unroll
+  for (int f = 0; f < NFT; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[f], one_h0, acc[f], 0, 0, 0);
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_to(const f32x16 (&acc)[8], f32x16* out) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[t][r] = fmaxf(acc[t][r], 0.f);
+}
+
+__global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
+  const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * RM;
+  const int m = m0 + j;
+  const bool valid = m < a.M;
+  const int mc = valid ? m : a.M - 1;
+  const int ray = mc / a.N;
+  const float* rf = a.rayf + (size_t)ray * RAYF;
+  const float4* wp = a.wp;
+
+  // first fragments of layer 0 and the ray-constant direction vector are requested before anything else
+  WStage<8> st0;
+  stage_load<8, 8>(wp + seg_off4(SEG_L0) + lane, 0, st0);
+
+  // ---- sample point and its encoding, straight into B-operand registers:
+  // gp[t][4g + s] = gamma_p[k], k = 32t + 8g + 4h + s  (4 consecutive k = two (sin, cos) pairs)
+  float p[3];
+  sample_point(rf, a.t[mc], p);
+  if (a.pts_dbg && valid && h == 0) {
+    a.pts_dbg[(size_t)m * 3 + 0] = p[0];
+    a.pts_dbg[(size_t)m * 3 + 1] = p[1];
+    a.pts_dbg[(size_t)m * 3 + 2] = p[2];
+  }
+  f32x16 gp[2];
+#pragma unroll
+  for (int g8 = 0; g8 < 8; ++g8) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int pi = 4 * g8 + 2 * h + e;  // (sin, cos) pair index: k = 2 pi
+      float sv = 0.f, cv = 0.f;
+      if (pi < 30) {
+        const int c = pi / 10, l = pi - 10 * c;
+        const float x = (c == 0) ? p[0] : ((c == 1) ? p[1] : p[2]);
+        const float ph = x * __uint_as_float(kFreqPointBits[l]);
+        sincos_phase(ph, sv, cv);
+      }
+      gp[g8 >> 2][4 * (g8 & 3) + 2 * e] = sv;
+      gp[g8 >> 2][4 * (g8 & 3) + 2 * e + 1] = cv;
+    }
+  }
+  if (a.gp_dbg && valid) {
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 8 * g8 + 4 * h + s;
+        if (k < POINT_DIM) a.gp_dbg[(size_t)m * POINT_DIM + k] = gp[g8 >> 2][4 * (g8 & 3) + s];
+      }
+  }
+
+  f32x16 acc[8], act[8];
+  constexpr int L256 = 8 * 32 * 64;  // float4 per 256x256 segment
+
+  float bv[8];
+  // ---- layer 0: 60(64) -> 256
+  bias_load<8>(a.w.p[B_L0], lane, bv);
+  reg_layer<8, 8, 32, 8, true>(wp + seg_off4(SEG_L0), wp + seg_off4(SEG_L1), lane, gp, acc, st0);
+  add_bias<8>(bv, lane, acc);
+  relu_to<8>(acc, act);
+  // ---- layers 1..3 (the segment after L3 is L4A: same shape)
+#pragma unroll 1
+  for (int l = 1; l <= 3; ++l) {
+    const float4* seg = wp + seg_off4(SEG_L1) + (size_t)(l - 1) * L256;
+    bias_load<8>(a.w.p[2 * l + 1], lane, bv);
+    reg_layer<32, 8, 32, 8, true>(seg, seg + L256, lane, act, acc, st0);
+    add_bias<8>(bv, lane, acc);
+    relu_to<8>(acc, act);
+  }
+  // ---- layer 4: cat(h3, gamma_p), hidden first (nerf.py:109)
+  bias_load<8>(a.w.p[9], lane, bv);
+  reg_layer<32, 8, 8, 8, true>(wp + seg_off4(SEG_L4A), wp + seg_off4(SEG_L4B), lane, act, acc, st0);
+  reg_layer<8, 8, 32, 8, false>(wp + seg_off4(SEG_L4B), wp + seg_off4(SEG_L5), lane, gp, acc, st0);
+  add_bias<8>(bv, lane, acc);
+  relu_to<8>(acc, act);
+  // ---- layers 5..7 (the segment after L7 is point_info: same shape)
+#pragma unroll 1
+  for (int l = 5; l <= 7; ++l) {
+    const float4* seg = wp + seg_off4(SEG_L5) + (size_t)(l - 5) * L256;
+    bias_load<8>(a.w.p[2 * l + 1], lane, bv);
+    reg_layer<32, 8, 32, 8, true>(seg, seg + L256, lane, act, acc, st0);
+    add_bias<8>(bv, lane, acc);
+    relu_to<8>(acc, act);
+  }
+  // ---- sigma head on h7 (VALU): sigma = |w_sigma . h7 + b|  (nerf.py:94, 115)
+  {
+    const float* ws = a.w.p[W_SIGMA] + 4 * h;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 wq = *reinterpret_cast<const float4*>(ws + 32 * t + 8 * g);
+        s = __builtin_fmaf(act[t][4 * g + 0], wq.x, s);
+        s = __builtin_fmaf(act[t][4 * g + 1], wq.y, s);
+        s = __builtin_fmaf(act[t][4 * g + 2], wq.z, s);
+        s = __builtin_fmaf(act[t][4 * g + 3], wq.w, s);
+      }
+    s += __shfl_xor(s, 32);
+    if (valid && h == 0) a.sigma[m] = fabsf(s + a.w.p[B_SIGMA][0]);
+  }
+  // ---- point_info: 256 -> 256, no activation; next segment = dir_info (4 tiles)
+  bias_load<8>(a.w.p[B_PI], lane, bv);
+  reg_layer<32, 8, 32, 4, true>(wp + seg_off4(SEG_PI), wp + seg_off4(SEG_DIR), lane, act, acc, st0);
+  add_bias<8>(bv, lane, acc);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) act[t] = acc[t];
+  // ---- dir_info: cat(gamma_d, feat) -> 128, ReLU.  gamma_d part + bias = dvec (per ray), the accumulator start
+  {
+    const float* dv = a.dvec + (size_t)ray * HALF + 4 * h;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 q = *reinterpret_cast<const float4*>(dv + 32 * f + 8 * g);
+        acc[f][4 * g + 0] = q.x;
+        acc[f][4 * g + 1] = q.y;
+        acc[f][4 * g + 2] = q.z;
+        acc[f][4 * g + 3] = q.w;
+      }
+  }
+  reg_layer<32, 4, 32, 4, false>(wp + seg_off4(SEG_DIR), nullptr, lane, act, acc, st0);
+  // ---- colour head (VALU): rgb = sigmoid(W_c relu(.) + b)  (nerf.py:99, 119)
+  {
+    const float* wc = a.w.p[W_COLOR] + 4 * h;
+    float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 q0 = *reinterpret_cast<const float4*>(wc + 32 * t + 8 * g);
+        const float4 q1 = *reinterpret_cast<const float4*>(wc + HALF + 32 * t + 8 * g);
+        const float4 q2 = *reinterpret_cast<const float4*>(wc + 2 * HALF + 32 * t + 8 * g);
+        const float c0 = fmaxf(acc[t][4 * g + 0], 0.f), c1 = fmaxf(acc[t][4 * g + 1], 0.f);
+        const float c2 = fmaxf(acc[t][4 * g + 2], 0.f), c3 = fmaxf(acc[t][4 * g + 3], 0.f);
+        z0 = __builtin_fmaf(c3, q0.w, __builtin_fmaf(c2, q0.z, __builtin_fmaf(c1, q0.y, __builtin_fmaf(c0, q0.x, z0))));
+        z1 = __builtin_fmaf(c3, q1.w, __builtin_fmaf(c2, q1.z, __builtin_fmaf(c1, q1.y, __builtin_fmaf(c0, q1.x, z1))));
+        z2 = __builtin_fmaf(c3, q2.w, __builtin_fmaf(c2, q2.z, __builtin_fmaf(c1, q2.y, __builtin_fmaf(c0, q2.x, z2))));
+      }
+    z0 += __shfl_xor(z0, 32);
+    z1 += __shfl_xor(z1, 32);
+    z2 += __shfl_xor(z2, 32);
+    if (valid && h == 0) {
+      const float* bc = a.w.p[B_COLOR];
+      a.rgb[(size_t)m * 3 + 0] = 1.0f / (1.0f + expf(-(z0 + bc[0])));
+      a.rgb[(size_t)m * 3 + 1] = 1.0f / (1.0f + expf(-(z1 + bc[1])));
+      a.rgb[(size_t)m * 3 + 2] = 1.0f / (1.0f + expf(-(z2 + bc[2])));
+    }
+  }
+}
+
+hipError_t launch_field_fwd_reg(const FieldArgs& a, hipStream_t st) {
+  const int tiles = (a.M + RM - 1) / RM;
+  hipLaunchKernelGGL(k_field_fwd_reg, dim3(tiles), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace nerf

@@ -307,4 +307,6 @@ def test_sum_of_shard_gradients_equals_full_batch(oracle, pkg, dev):
     a = grads(slice(0, B // 2), r0)
     b = grads(slice(B // 2, B), r0)
     for f, x, y in zip(full, a, b):
-        assert l2_rel(x + y, f) < 2e-5
+        # relative to the size of the summands: the two halves may cancel (e.g. the scalar sigma bias)
+        scale = float(x.double().norm() + y.double().norm())
+        assert float((x.double() + y.double() - f.double()).norm()) < 2e-5 * scale
