@@ -125,6 +125,23 @@ int nerf_hip_profile_begin(int max_launches);
 int nerf_hip_profile_end(double* ms_sum, int* count, int n_kernels);
 
 /* ---------------------------------------------------------------------------------------------
+ * Rows f1/f2 of the scope table: what the caller does around the hot path once the renderer is fast.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Fused Adam update of all 24 parameter tensors in one launch: torch.optim.Adam semantics as constructed at
+ * nerf.py:425 (no weight decay, no amsgrad).  exp_avg / exp_avg_sq: flat [593,924] f32 moment buffers in
+ * parameters() order (caller allocated, zero before step 1).  step = 1, 2, ...; lr = this step's learning rate
+ * (the LambdaLR of nerf.py:426 is evaluated by the caller). */
+int nerf_hip_adam_step(float* const* params24, const float* const* grads24, float* exp_avg, float* exp_avg_sq,
+                       int step, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* GPU-resident replacement of NeRFDataset.__getitem__ + DataLoader collation (loader.py:119-133): for B flat pixel
+ * indices into pixels[n_pic*H*W][3] (loader.py:88) and poses17[n_pic][17] (f32) writes row, col, pic [B] i64,
+ * pix_val [B,3] and poses_bound [B,17] f32 -- the tuple nerf.py:458 iterates over, already on the device. */
+int nerf_hip_gather_rays(const int64_t* index, const float* pixels, const float* poses17, int B, int H, int W,
+                         int64_t* row, int64_t* col, int64_t* pic, float* pix_val, float* poses_bound, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Stage entry points (same kernels as nerf_hip_forward; exposed so each row of the hot-path
  * table can be parity-checked on its own).
  * ------------------------------------------------------------------------------------------- */

@@ -28,6 +28,8 @@ _PROTOS = {
     "nerf_hip_read_status": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_uint32), _p]),
     "nerf_hip_profile_begin": (C.c_int, [C.c_int]),
     "nerf_hip_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
+    "nerf_hip_adam_step": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _p]),
+    "nerf_hip_gather_rays": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p]),
     "nerf_hip_rays": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p]),
     "nerf_hip_field": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_size_t, _p]),
     "nerf_hip_coarse_composite": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),

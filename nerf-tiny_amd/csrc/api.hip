@@ -5,6 +5,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 
 #include "kernels.h"
@@ -463,6 +464,43 @@ int nerf_hip_coarse_composite(const float* t_c, const float* sigma_c, const floa
   ca.delta0_mode = 1; ca.delta0 = delta0;
   ca.w_c = w_c; ca.C_coarse = C_coarse; ca.t_f = t_f; ca.status = status;
   HIP_TRY(launch_coarse(ca, static_cast<hipStream_t>(stream)));
+  return NERF_HIP_OK;
+}
+
+static const int kParamNumel[24] = {256 * 60, 256, 256 * 256, 256, 256 * 256, 256, 256 * 256, 256, 256 * 316, 256, 256 * 256, 256,
+                                     256 * 256, 256, 256 * 256, 256, 256, 1, 256 * 256, 256, 128 * 280, 128, 3 * 128, 3};
+
+int nerf_hip_adam_step(float* const* params24, const float* const* grads24, float* exp_avg, float* exp_avg_sq, int step, float lr,
+                       float beta1, float beta2, float eps, void* stream) {
+  if (!params24 || !grads24 || !exp_avg || !exp_avg_sq || step < 1) return fail(NERF_HIP_ERR_ARG, "bad argument");
+  AdamArgs a;
+  memset(&a, 0, sizeof(a));
+  int off = 0;
+  for (int i = 0; i < 24; ++i) {
+    if (!params24[i] || !grads24[i]) return fail(NERF_HIP_ERR_ARG, "null tensor %d", i);
+    a.param[i] = params24[i]; a.grad[i] = grads24[i]; a.numel[i] = kParamNumel[i]; a.offset[i] = off;
+    off += kParamNumel[i];
+  }
+  a.m = exp_avg; a.v = exp_avg_sq;
+  // bias corrections in double like torch's Python scalars
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.bias2_sqrt = (float)sqrt(bc2);
+  a.one_minus_beta1 = 1.0f - beta1; a.beta2 = beta2; a.one_minus_beta2 = 1.0f - beta2; a.eps = eps;
+  HIP_TRY(launch_adam(a, static_cast<hipStream_t>(stream)));
+  return NERF_HIP_OK;
+}
+
+int nerf_hip_gather_rays(const int64_t* index, const float* pixels, const float* poses17, int B, int H, int W, int64_t* row,
+                         int64_t* col, int64_t* pic, float* pix_val, float* poses_bound, void* stream) {
+  if (!index || !pixels || !poses17 || !row || !col || !pic || !pix_val || !poses_bound || B < 1 || H < 1 || W < 1)
+    return fail(NERF_HIP_ERR_ARG, "bad argument");
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.index = reinterpret_cast<const long long*>(index); g.pixels = pixels; g.poses = poses17; g.B = B; g.H = H; g.W = W;
+  g.row = reinterpret_cast<long long*>(row); g.col = reinterpret_cast<long long*>(col); g.pic = reinterpret_cast<long long*>(pic);
+  g.pix_val = pix_val; g.poses_bound = poses_bound;
+  HIP_TRY(launch_gather_rays(g, static_cast<hipStream_t>(stream)));
   return NERF_HIP_OK;
 }
 

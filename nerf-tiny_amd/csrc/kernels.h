@@ -166,4 +166,29 @@ size_t merge_bwd_lds_bytes(int N);
 hipError_t launch_merge_bwd(const MergeBwdArgs& a, hipStream_t st);
 hipError_t launch_coarse_bwd(const CoarseBwdArgs& a, hipStream_t st);
 
+struct AdamArgs {
+  float* param[24];
+  const float* grad[24];
+  int numel[24];
+  int offset[24];          // start of tensor t inside the flat moment buffers
+  float* m;                // exp_avg, flat [593,924]
+  float* v;                // exp_avg_sq
+  float step_size;         // lr / (1 - beta1^t)
+  float bias2_sqrt;        // sqrt(1 - beta2^t)
+  float one_minus_beta1, beta2, one_minus_beta2, eps;
+};
+
+struct GatherArgs {
+  const long long* index;  // [B] flat pixel indices
+  const float* pixels;     // [n_pic*H*W][3]
+  const float* poses;      // [n_pic][17] f32
+  int B, H, W;
+  long long *row, *col, *pic;  // [B] i64 (the dtypes the reference's collate produces)
+  float* pix_val;          // [B][3]
+  float* poses_bound;      // [B][17] f32
+};
+
+hipError_t launch_adam(const AdamArgs& a, hipStream_t st);
+hipError_t launch_gather_rays(const GatherArgs& a, hipStream_t st);
+
 }  // namespace nerf

@@ -1,0 +1,39 @@
+"""Driver with the reference's command line (``python main.py --conf=lego``, main.py:10-56) for the MI355X path.
+
+The reference's own main.py cannot run against its shipped configs (three ini keys are missing,
+``trainer()`` is called without its required argument, ``LR_MILESTONE`` is parsed into characters); this driver reads
+the same 17 keys with defaults for the three missing ones, parses the milestone list properly and calls
+``trainer("train")``.  ``--synthetic`` trains on a procedural scene when the datasets are not on disk.
+"""
+import argparse
+import ast
+import os
+import sys
+from configparser import ConfigParser
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+if __name__ == "__main__":
+    import nerf_tiny_amd as P
+
+    ap = argparse.ArgumentParser(description="NeRF argument parser.")
+    ap.add_argument("--conf", type=str, default="lego")
+    ap.add_argument("--conf-dir", type=str, default=os.path.join(HERE, "conf"))
+    ap.add_argument("--synthetic", action="store_true", help="procedural scene instead of IMG_DIR")
+    ap.add_argument("--total-iter", type=int, default=None)
+    args = ap.parse_args()
+    conf = ConfigParser()
+    conf.read(os.path.join(args.conf_dir, args.conf + ".ini"))
+    c = lambda k, d=None: conf.get(args.conf, k, fallback=d)
+    kw = dict(gpu=int(c("GPU", 0)), img_dir=c("IMG_DIR"), results_path=c("RESULTS_PATH", "./results/"), ckpt_path=c("CKPT_PATH", "./checkpoint/"),
+              low_res=int(c("LOW_RES", 1)), total_iter=int(args.total_iter or c("TOTAL_ITER", c("EPOCH", 100000))), batch_ray=int(c("BATCH_RAY", 400)),
+              learning=float(c("LEARNING", 1e-3)), lr_gamma=float(c("LR_GAMMA", 0.1)), lr_milestone=list(ast.literal_eval(c("LR_MILESTONE", "[10, 200]"))),
+              n_coarse=int(c("N_COARSE", 64)), n_fine=int(c("N_FINE", 128)), data_type=c("DATA_TYPE", "sync"), step=int(c("STEP", 100)),
+              decay_end=float(c("DECAY_END", 200000)), sched=c("SCHED", "EXP"), continue_=ast.literal_eval(c("CONTINUE", "False")))
+    if args.synthetic:
+        scene = P.data.synthetic_scene(n_pic=8, H=64, W=64)
+        kw["datasets"] = {"train": scene, "val": scene, "test": scene}
+    run = P.NeRFRunner(**kw)
+    run.trainer("train")
+    run.display()

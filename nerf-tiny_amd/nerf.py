@@ -200,3 +200,11 @@ class _RayLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dCc, dCf = ctx.saved_tensors
         return g * dCc, g * dCf, None
+
+
+def __getattr__(name):  # `from nerf import NeRFRunner` (main.py:4) without a circular import at module load
+    if name == "NeRFRunner":
+        from .train import NeRFRunner
+
+        return NeRFRunner
+    raise AttributeError(name)

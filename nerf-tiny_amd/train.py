@@ -1,0 +1,208 @@
+"""Train-loop side of the hot path: the fused optimizer and a runner with the
+reference's ``NeRFRunner`` surface (``/root/reference/nerf.py:353-530``) that keeps the device busy -- GPU-resident
+ray sampler, fused Adam, no per-iteration host sync (the reference flushes TensorBoard, copies ``C_true`` to the host
+and updates a preview image every iteration, nerf.py:478-483).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import time
+
+import torch
+
+from . import _abi
+from .data import DeviceRays, NeRFDataset
+from .nerf import NeRFModel
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` semantics (nerf.py:425: betas (0.9, 0.999), eps 1e-7, no weight decay) for the 24 tensors of
+    ``model.network`` in ONE kernel launch (``nerf_hip_adam_step``).  A ``torch.optim.Optimizer`` subclass, so the
+    reference's ``LambdaLR`` / ``MultiStepLR`` schedulers drive ``param_groups[0]['lr']`` unchanged; ``state_dict`` uses
+    Adam's keys (``step``, ``exp_avg``, ``exp_avg_sq``)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if len(self.param_groups) != 1 or len(ps) != 24:
+            raise ValueError("FusedAdam expects one group holding the 24 tensors of NeRFModel.network.parameters()")
+        n = sum(p.numel() for p in ps)
+        self._m = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        self._v = torch.zeros_like(self._m)
+        o = 0
+        for p in ps:
+            st = self.state[p]
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = self._m[o:o + p.numel()].view_as(p)
+            st["exp_avg_sq"] = self._v[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self._step = 0
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        ps = self.param_groups[0]["params"]
+        o = 0
+        for p in ps:  # re-alias the flat buffers
+            st = self.state[p]
+            self._m[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
+            self._v[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+            st["exp_avg"] = self._m[o:o + p.numel()].view_as(p)
+            st["exp_avg_sq"] = self._v[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self._step = int(self.state[ps[0]]["step"])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        ps = g["params"]
+        if any(p.grad is None for p in ps):
+            raise RuntimeError("FusedAdam.step: every parameter needs a gradient")
+        self._step += 1
+        b1, b2 = g["betas"]
+        dev = ps[0].device
+        _abi.check(_abi.lib().nerf_hip_adam_step(_abi.ptr_array(ps), _abi.ptr_array([p.grad.contiguous() for p in ps]),
+                                                 self._m.data_ptr(), self._v.data_ptr(), self._step, float(g["lr"]), float(b1),
+                                                 float(b2), float(g["eps"]), torch.cuda.current_stream(dev).cuda_stream))
+        for p in ps:
+            self.state[p]["step"] = torch.tensor(float(self._step))
+        return None
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def flush(self):
+        pass
+
+
+def _writer():
+    try:
+        from torch.utils.tensorboard import SummaryWriter  # absent offline
+
+        return SummaryWriter()
+    except Exception:
+        return _NullWriter()
+
+
+class NeRFRunner:
+    """The reference's runner surface: same 17 constructor arguments (nerf.py:354-372), ``trainer(mode)`` (nerf.py:445)
+    and ``display()`` (nerf.py:503).  ``mode`` defaults to "train" so the reference's ``main.py:55`` call works.
+    Extra keyword-only arguments: ``datasets`` (dict mode -> dataset, to run without files), ``log_every`` (host sync
+    period; the reference syncs every iteration)."""
+
+    def __init__(self, gpu=0, img_dir="../nerf_synthetic/lego/", results_path="./results/", ckpt_path="./checkpoint/", low_res=1,
+                 total_iter=100000, batch_ray=400, learning=1e-3, lr_gamma=0.1, lr_milestone=(10, 200), n_coarse=64, n_fine=128,
+                 data_type="sync", step=100, decay_end=200000, sched="EXP", continue_=False, *, datasets=None, log_every=None,
+                 seed=624):
+        from . import nerf as _nerf
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("NeRFRunner needs a ROCm device: the MI355X path has no CPU fallback")
+        self.device = torch.device("cuda:" + str(gpu))
+        _nerf.device = self.device  # module global like nerf.py:387
+        torch.cuda.set_device(self.device)
+        self.writer = _writer()
+        self.start_time = time.strftime("%m-%d-%H-%M-%S", time.localtime())
+        self.results_path, self.ckpt_path, self.low_res = results_path, ckpt_path, low_res
+        self.total_iter, self.batch_ray, self.step, self.decay_end = total_iter, batch_ray, step, decay_end
+        self.log_every = log_every or step
+        self.model = NeRFModel(num_coarse=n_coarse, num_fine=n_fine, batch_ray=batch_ray).to(self.device)
+
+        # resume: newest "<anything>_<iter>.pkl" (nerf.py:404-415)
+        last_iter, last_ckpt = -1, None
+        if continue_:
+            for f in glob.glob(ckpt_path + "*.pkl"):
+                it = int(f.split("_")[-1][:-4])
+                if it > last_iter:
+                    last_iter, last_ckpt = it, f
+        if last_ckpt is not None:
+            self.model = torch.load(last_ckpt, weights_only=False).to(self.device)
+        self.last_iter = last_iter
+
+        def ds(mode):
+            if datasets is not None:
+                return datasets[mode]
+            return NeRFDataset(root_dir=img_dir, low_res=low_res, transform=None, type=data_type, mode=mode)
+
+        self.train_dataset, self.val_dataset, self.disp_dataset = ds("train"), ds("val"), ds("test")
+        self.train_rays = DeviceRays(self.train_dataset, self.device, seed)
+        self.val_rays = DeviceRays(self.val_dataset, self.device, seed + 1)
+        self.disp_rays = DeviceRays(self.disp_dataset, self.device, seed + 2)
+        self.height, self.width, self.focal = self.train_dataset.height, self.train_dataset.width, self.train_dataset.focal
+        self.num_pic = self.train_dataset.pic_num
+        # inverse intrinsics, transposed (nerf.py:433)
+        self.K_inv = torch.tensor([[1.0, 0.0, -0.5 * self.width], [0.0, -1.0, 0.5 * self.height], [0.0, 0.0, -self.focal]]).to(torch.float).transpose(0, 1)
+
+        self.optimizer = FusedAdam([{"params": list(self.model.network.parameters()), "initial_lr": learning}], lr=learning,
+                                   betas=(0.9, 0.999), eps=1e-7)
+        if sched == "EXP":  # nerf.py:426, including its post-decay_end multiplier lr_gamma * learning
+            self.scheduler = torch.optim.lr_scheduler.LambdaLR(
+                self.optimizer, lr_lambda=lambda it: lr_gamma ** (it / decay_end) if it < decay_end else lr_gamma * learning,
+                last_epoch=self.last_iter)
+        else:
+            self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, list(lr_milestone), lr_gamma, last_epoch=self.last_iter)
+
+    # nerf.py:445-499
+    def trainer(self, mode="train"):
+        rays = {"train": self.train_rays, "val": self.val_rays, "disp": self.disp_rays}[mode]
+        it = self.last_iter + 1
+        t0, n0 = time.perf_counter(), it
+        while it < self.total_iter:
+            for row, col, pix_val, poses_bound, pic in rays.epoch(self.batch_ray):
+                self.optimizer.zero_grad(set_to_none=True)
+                self.model.train()
+                C_coarse, C_fine = self.model(row, col, poses_bound, self.K_inv)
+                loss = self.model.ray_loss(C_coarse, C_fine, pix_val)
+                loss.backward()
+                self.optimizer.step()
+                self.scheduler.step()
+                if (it + 1) % self.log_every == 0:  # the only host sync of the loop
+                    lv = float(loss.detach())
+                    dt = time.perf_counter() - t0
+                    self.writer.add_scalar("loss/" + mode, lv, it)
+                    self.writer.add_scalar("lr/" + mode, self.optimizer.param_groups[0]["lr"], it)
+                    self.writer.flush()
+                    print(f"[ITER] {it} [LOSS] {lv:.4f} [LR] {self.optimizer.param_groups[0]['lr']:.3e} "
+                          f"[{(it + 1 - n0) * self.batch_ray / max(dt, 1e-9):,.0f} rays/s]")
+                if (it + 1) % self.step == 0:
+                    os.makedirs(self.ckpt_path, exist_ok=True)
+                    torch.save(self.model, self.ckpt_path + self.start_time + "_" + str(it) + ".pkl")
+                it += 1
+                if it >= self.total_iter:
+                    break
+            if mode == "val":
+                break
+        self.last_iter = it - 1
+        return self.last_iter
+
+    # nerf.py:503-530
+    def display(self, save=True):
+        rays = self.disp_rays
+        result = torch.full((rays.pic_num, self.height, self.width, 3), 1.0, device=self.device)
+        self.model.eval()
+        with torch.no_grad():
+            for row, col, pix_val, poses_bound, pic in rays.epoch(self.batch_ray, shuffle=False):  # tail < batch stays white
+                _, C_fine = self.model(row, col, poses_bound, self.K_inv)
+                result[pic, row, col] = C_fine
+        result = result.cpu().numpy()
+        if save:
+            save_dir = self.results_path + self.start_time + "/"
+            os.makedirs(save_dir, exist_ok=True)
+            try:
+                import matplotlib.pyplot as plt
+
+                for i in range(rays.pic_num):
+                    plt.imsave(save_dir + str(i) + ".jpg", result[i].clip(0, 1))
+            except Exception as e:  # pragma: no cover
+                print("display: could not write images:", e)
+            try:
+                import imageio
+                import numpy as np
+
+                imageio.mimwrite(self.results_path + self.start_time + "_" + str(self.last_iter) + ".mp4",
+                                 (result * 255.0).astype(np.uint8), fps=30)
+            except Exception:
+                pass  # imageio is optional (absent offline)
+        return result

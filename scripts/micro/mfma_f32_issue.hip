@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
   float a = a0 + threadIdx.x * 1e-3f, b = b0;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 32 / NACC * 4; ++u)
 #pragma unroll
       for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
   }
@@ -21,20 +21,22 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
 template <int NACC>
 void run(int wgs_per_cu, const char* label) {
   float* out; hipMalloc(&out, 4 * 256 * 256 * 8);
-  const int iters = 20000;
+  const int iters = 4000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k<NACC>, dim3(256 * wgs_per_cu), dim3(256), 0, 0, out, 100, 1.f, 1.f);
   hipEventRecord(e0);
   hipLaunchKernelGGL(k<NACC>, dim3(256 * wgs_per_cu), dim3(256), 0, 0, out, iters, 1.f, 1.f);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  double mfma = (double)256 * wgs_per_cu * 4 * iters * 4 * NACC;
+  double mfma = (double)256 * wgs_per_cu * 4 * iters * (32 / NACC * 4) * NACC;
   double flops = mfma * 32 * 32 * 2 * 2;
   printf("%-34s %8.3f ms  %7.1f TFLOP/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", label, ms, flops / ms / 1e9,
          ms * 1e-3 * 2.4e9 / (mfma / 1024));
   hipFree(out);
 }
 int main() {
+  run<8>(1, "1 wave/SIMD, 8 accumulators, 128 MFMA/iter");
+  run<8>(2, "2 waves/SIMD, 8 accumulators, 128 MFMA/iter");
   run<4>(1, "1 wave/SIMD, 4 accumulators");
   run<4>(2, "2 waves/SIMD, 4 accumulators");
   run<4>(4, "4 waves/SIMD, 4 accumulators");

@@ -1,0 +1,71 @@
+"""CPU: the data-side restatements (rows f1/f4): pre-processors and the per-pixel dataset against hand-built files."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_blender(tmp, n=3, H=6, W=8):
+    from PIL import Image
+
+    root = str(tmp) + "/"
+    os.makedirs(root + "train", exist_ok=True)
+    frames = []
+    rng = np.random.default_rng(0)
+    imgs = []
+    for i in range(n):
+        rgba = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+        Image.fromarray(rgba, "RGBA").save(root + f"train/r_{i}.png")
+        imgs.append(rgba)
+        m = np.eye(4)
+        m[:3, :4] = rng.standard_normal((3, 4))
+        frames.append({"file_path": f"./train/r_{i}", "transform_matrix": m.tolist()})
+    json.dump({"camera_angle_x": 0.69, "frames": frames}, open(root + "transforms_train.json", "w"))
+    return root, imgs, frames
+
+
+def test_blender_preprocess_and_dataset(pkg, tmp_path):
+    root, imgs, frames = _write_blender(tmp_path)
+    ds = pkg.data.NeRFDataset(root_dir=root, low_res=1, transform=None, type="sync", mode="train")
+    H, W = 6, 8
+    assert (ds.pic_num, ds.height, ds.width) == (3, H, W) and len(ds) == 3 * H * W
+    pb = np.load(root + "train.npy")
+    assert pb.shape == (3, 17)
+    focal = 0.5 * W / np.tan(0.5 * 0.69)
+    m0 = np.array(frames[0]["transform_matrix"])[:3, :4]
+    want = np.concatenate((np.concatenate((m0, [[H], [W], [focal]]), axis=1).flatten(), [2.0, 6.0]))  # loader.py:33
+    assert np.allclose(pb[0], want)
+    # __getitem__: index -> (row, column, pixel over white background, pose row, picture)   loader.py:119-133
+    idx = 1 * H * W + 4 * W + 5
+    row, col, pix, pose, pic = ds[idx]
+    assert (row, col, pic) == (4, 5, 1) and np.array_equal(pose, pb[1])
+    a = imgs[1][4, 5].astype(np.float64)
+    alpha = a[3] / 255.0
+    blend = np.round(a[:3] * alpha + 255.0 * (1 - alpha)) / 255.0  # PIL paste with mask
+    assert np.allclose(pix.numpy(), blend, atol=1.5 / 255)
+
+
+def test_llff_convert(pkg, tmp_path):
+    root = str(tmp_path) + "/"
+    rng = np.random.default_rng(1)
+    src = rng.standard_normal((4, 17))
+    np.save(root + "poses_bounds.npy", src)
+    pkg.data.convert_npy(root)
+    dst = np.load(root + "new.npy")
+    for i in range(4):
+        pose = src[i, :15].reshape(3, 5)
+        c2w = pose[:, :4]
+        new_ctw = np.concatenate((c2w[:, 1], -c2w[:, 0], c2w[:, 2]), axis=0)  # loader.py:48
+        want = np.concatenate((new_ctw.reshape(3, 3).transpose(), c2w[:, 3].reshape(3, 1), pose[:, 4].reshape(3, 1)), axis=1).flatten()
+        assert np.allclose(dst[i, :15], want) and np.allclose(dst[i, 15:], src[i, 15:])
+
+
+def test_synthetic_scene_shapes(pkg):
+    ds = pkg.data.synthetic_scene(n_pic=3, H=8, W=10)
+    assert len(ds) == 3 * 8 * 10
+    row, col, pix, pose, pic = ds[2 * 80 + 3 * 10 + 7]
+    assert (row, col, pic) == (3, 7, 2) and pose.shape == (17,) and pix.shape == (3,)
+    R = pose[:15].reshape(3, 5)[:, :3]
+    assert np.allclose(R.T @ R, np.eye(3), atol=1e-9)  # proper camera frame
