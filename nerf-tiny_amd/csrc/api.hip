@@ -203,8 +203,8 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     fa.save = at<float>(ws, L.save); fa.masks = at<uint16_t>(ws, L.masks); fa.spre = at<float>(ws, L.spre);
     fa.row0 = 0; fa.tile0 = 0; fa.tiles_tot = tiles_c + tiles_f; fa.Mtot = (long long)B * (Nc + Nf);
   }
-  const bool tile_kernel = save || (flags & NERF_HIP_FORCE_TILE_KERNEL);
-  { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(tile_kernel ? launch_field_fwd(fa, save, st) : launch_field_fwd_reg(fa, st)); }
+  const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
+  { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(tile_kernel ? launch_field_fwd(fa, save, st) : launch_field_fwd_reg(fa, save, st)); }
 
   CoarseArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -223,7 +223,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.sigma = at<float>(ws, L.sig_f);
   fa.N = Nf; fa.M = B * Nf;
   if (save) { fa.row0 = B * Nc; fa.tile0 = tiles_c; }
-  { ProfScope ps(NERF_HIP_K_FIELD_FINE, st); HIP_TRY(tile_kernel ? launch_field_fwd(fa, save, st) : launch_field_fwd_reg(fa, st)); }
+  { ProfScope ps(NERF_HIP_K_FIELD_FINE, st); HIP_TRY(tile_kernel ? launch_field_fwd(fa, save, st) : launch_field_fwd_reg(fa, save, st)); }
 
   MergeArgs ma;
   memset(&ma, 0, sizeof(ma));
@@ -449,7 +449,7 @@ int nerf_hip_field(const float* const* weights24, const int64_t* row, const int6
   fa.dvec = at<float>(ws, L.dvec);
   fa.t = t; fa.rgb = rgb; fa.sigma = sigma; fa.pts_dbg = pts; fa.gp_dbg = gamma_p;
   fa.N = N; fa.M = B * N;
-  HIP_TRY(launch_field_fwd_reg(fa, st));
+  HIP_TRY(launch_field_fwd_reg(fa, false, st));
   return NERF_HIP_OK;
 }
 

@@ -33,18 +33,55 @@ __device__ __forceinline__ void stage_load(const float4* __restrict__ seg_lane, 
 
 __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
-// acc[f] (+)= sum_k W[f-tile][k] * in[k]   over KB k-blocks of 8; in = KB/4 register tiles in accumulator layout.
+// acc[f] (+)= sum_k W[f-tile][k] * act(prev)[k]   over KB k-blocks of 8.
+// prev = KB/4 register tiles in accumulator layout; RELU_IN: they are the previous layer's raw accumulators and the
+// ReLU is applied lazily, one tile at a time, two k-blocks before the tile is first used -- VALU work in the shadow of
+// the MFMA stream instead of a serial epilogue between layers.
 // Two fragment stages: the A fragments of k-block kb+1 (or k-block 0 of the NEXT segment: NKB k-blocks, NNFT tiles) are
 // requested at the top of k-block kb, i.e. 32 MFMAs = 2048 cycles before their first use; the scheduling barrier keeps
 // the compiler from sinking the requests towards their uses.  st0 holds k-block 0 on entry and the next segment's
-// k-block 0 on exit.
-template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT>
+// k-block 0 on exit.  bv (8 bias rows of this lane) != nullptr: one extra MFMA per tile starts the accumulator
+// at the bias (A = bias on every lane, B = 1 on lane half 0, C = 0).
+// Training (SAVE): the CONSUMER layer writes its activated input tiles to the row-major save buffer (lane (j, h) owns
+// the 16-byte groups 32t + 8g + 4h of row j) and, for ReLU inputs, the u16 mask words in the tile kernels' layout.
+struct SaveIn {
+  float* rows;      // &save[tensor][row0 + m0 + j][4h]   (null = nothing to save)
+  uint16_t* mask;   // &masks[layer][tile64][st][h*32 + j] (null = no masks); entry (f, wv) at + (f*2)*256 + wv*64
+  bool live;        // row inside the pass
+};
+
+template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT, bool RELU_IN, bool SAVE = false>
 __device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
-                                          const f32x16* in, f32x16 (&acc)[8], WStage<8>& st0) {
+                                          const f32x16* prev, f32x16* acc, WStage<8>& st0, const float* bv,
+                                          const SaveIn sv = SaveIn{nullptr, nullptr, false}) {
+  constexpr int KT = KB / 4;
   const float4* sl = seg + lane;
   const float4* nl = next_seg + lane;
   WStage<8> st1;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (bv != nullptr) {  // accumulators start at the bias (same rounding order as ATen's addmm and as k_field_fwd)
+    const float one_h0 = (lane < 32) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int f = 0; f < NFT; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[f], one_h0, zero, 0, 0, 0);
+  }
+  f32x16 tin[2];
+  auto activate = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tin[t & 1][r] = RELU_IN ? fmaxf(prev[t][r], 0.f) : prev[t][r];
+    if (SAVE && sv.rows != nullptr && sv.live) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(sv.rows + 32 * t + 8 * g) =
+            make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
+      if (RELU_IN && sv.mask != nullptr) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= (prev[t][r] > 0.f) ? (1u << r) : 0u;
+        sv.mask[((t & 1) * 2) * 256 + (t >> 1) * 64] = (uint16_t)bits;  // feature tile t = (wave t>>1, f = t&1)
+      }
+    }
+  };
+  activate(0);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     WStage<8>& ld = (kb & 1) ? st0 : st1;
@@ -57,18 +94,18 @@ __device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const 
       for (int f = 0; f < NNFT; ++f) ld.w[f] = nl[(size_t)(f * NKB) * 64];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if ((kb & 3) == 2 && (kb >> 2) + 1 < KT) activate((kb >> 2) + 1);  // next input tile, behind this k-block's MFMAs
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const float b = in[kb >> 2][4 * (kb & 3) + s];
+      const float b = tin[(kb >> 2) & 1][4 * (kb & 3) + s];
 #pragma unroll
       for (int f = 0; f < NFT; ++f) {
-        if (ZERO_INIT && kb == 0 && s == 0)
+        if (ZERO_INIT && bv == nullptr && kb == 0 && s == 0)
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(cur.w[f], s), b, zero, 0, 0, 0);
         else
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(cur.w[f], s), b, acc[f], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
   if (KB & 1) st0 = st1;  // (all segments have an even number of k-blocks: the next k-block 0 already sits in st0)
 }
@@ -79,22 +116,8 @@ __device__ __forceinline__ void bias_load(const float* __restrict__ bias, int la
 #pragma unroll
   for (int f = 0; f < NFT; ++f) bv[f] = bias[f * 32 + (lane & 31)];
 }
-// acc[f] += bias[f*32 + i] (one MFMA per tile: A = bias on every lane, B = 1 on lane half 0, 0 on half 1)
-template <int NFT>
-__device__ __forceinline__ void add_bias(const float (&bv)[8], int lane, f32x16 (&acc)[8]) {
-  const float one_h0 = (lane < 32) ? 1.0f : 0.0f;
-#pragma unroll
-  for (int f = 0; f < NFT; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[f], one_h0, acc[f], 0, 0, 0);
-}
 
-template <int NT>
-__device__ __forceinline__ void relu_to(const f32x16 (&acc)[8], f32x16* out) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[t][r] = fmaxf(acc[t][r], 0.f);
-}
-
+template <bool SAVE>
 __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * RM;
@@ -105,7 +128,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   const float* rf = a.rayf + (size_t)ray * RAYF;
   const float4* wp = a.wp;
 
-  // first fragments of layer 0 and the ray-constant direction vector are requested before anything else
+  // first fragments of layer 0 are requested before anything else
   WStage<8> st0;
   stage_load<8, 8>(wp + seg_off4(SEG_L0) + lane, 0, st0);
 
@@ -145,40 +168,43 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
       }
   }
 
-  f32x16 acc[8], act[8];
-  constexpr int L256 = 8 * 32 * 64;  // float4 per 256x256 segment
+  // training: where this lane's rows / mask words go (rows of the coarse pass first, then the fine pass)
+  const size_t MS = (size_t)a.Mtot * WIDTH;
+  float* const srow = SAVE ? a.save + (size_t)(a.row0 + m) * WIDTH + 4 * h : nullptr;
+  uint16_t* const mrow = SAVE ? a.masks + ((size_t)(a.tile0 + (m0 >> 6)) * 4 + ((m0 >> 5) & 1)) * 256 + h * 32 + j : nullptr;
+  const size_t MKS = (size_t)a.tiles_tot * 4 * 256;
+  auto sv_rows = [&](int tensor) { return SaveIn{SAVE ? srow + (size_t)tensor * MS : nullptr, nullptr, valid}; };
+  auto sv_relu = [&](int layer) { return SaveIn{SAVE ? srow + (size_t)layer * MS : nullptr, SAVE ? mrow + (size_t)layer * MKS : nullptr, valid}; };
 
+  // two accumulator sets ping-pong: a layer reads the previous layer's raw accumulators (ReLU applied lazily)
+  f32x16 A[8], B[8];
+  constexpr int L256 = 8 * 32 * 64;  // float4 per 256x256 segment
+  const float4* const sL1 = wp + seg_off4(SEG_L1);
+  const float4* const sL5 = wp + seg_off4(SEG_L5);
   float bv[8];
-  // ---- layer 0: 60(64) -> 256
+
+  // ---- layer 0: gamma_p 60(64) -> 256
   bias_load<8>(a.w.p[B_L0], lane, bv);
-  reg_layer<8, 8, 32, 8, true>(wp + seg_off4(SEG_L0), wp + seg_off4(SEG_L1), lane, gp, acc, st0);
-  add_bias<8>(bv, lane, acc);
-  relu_to<8>(acc, act);
+  reg_layer<8, 8, 32, 8, true, false, SAVE>(wp + seg_off4(SEG_L0), sL1, lane, gp, A, st0, bv, sv_rows(S_GP));
   // ---- layers 1..3 (the segment after L3 is L4A: same shape)
-#pragma unroll 1
-  for (int l = 1; l <= 3; ++l) {
-    const float4* seg = wp + seg_off4(SEG_L1) + (size_t)(l - 1) * L256;
-    bias_load<8>(a.w.p[2 * l + 1], lane, bv);
-    reg_layer<32, 8, 32, 8, true>(seg, seg + L256, lane, act, acc, st0);
-    add_bias<8>(bv, lane, acc);
-    relu_to<8>(acc, act);
-  }
+  bias_load<8>(a.w.p[3], lane, bv);
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1, sL1 + L256, lane, A, B, st0, bv, sv_relu(0));
+  bias_load<8>(a.w.p[5], lane, bv);
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1 + L256, sL1 + 2 * L256, lane, B, A, st0, bv, sv_relu(1));
+  bias_load<8>(a.w.p[7], lane, bv);
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1 + 2 * L256, wp + seg_off4(SEG_L4A), lane, A, B, st0, bv, sv_relu(2));
   // ---- layer 4: cat(h3, gamma_p), hidden first (nerf.py:109)
   bias_load<8>(a.w.p[9], lane, bv);
-  reg_layer<32, 8, 8, 8, true>(wp + seg_off4(SEG_L4A), wp + seg_off4(SEG_L4B), lane, act, acc, st0);
-  reg_layer<8, 8, 32, 8, false>(wp + seg_off4(SEG_L4B), wp + seg_off4(SEG_L5), lane, gp, acc, st0);
-  add_bias<8>(bv, lane, acc);
-  relu_to<8>(acc, act);
+  reg_layer<32, 8, 8, 8, true, true, SAVE>(wp + seg_off4(SEG_L4A), wp + seg_off4(SEG_L4B), lane, B, A, st0, bv, sv_relu(3));
+  reg_layer<8, 8, 32, 8, false, false>(wp + seg_off4(SEG_L4B), sL5, lane, gp, A, st0, nullptr);
   // ---- layers 5..7 (the segment after L7 is point_info: same shape)
-#pragma unroll 1
-  for (int l = 5; l <= 7; ++l) {
-    const float4* seg = wp + seg_off4(SEG_L5) + (size_t)(l - 5) * L256;
-    bias_load<8>(a.w.p[2 * l + 1], lane, bv);
-    reg_layer<32, 8, 32, 8, true>(seg, seg + L256, lane, act, acc, st0);
-    add_bias<8>(bv, lane, acc);
-    relu_to<8>(acc, act);
-  }
-  // ---- sigma head on h7 (VALU): sigma = |w_sigma . h7 + b|  (nerf.py:94, 115)
+  bias_load<8>(a.w.p[11], lane, bv);
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5, sL5 + L256, lane, A, B, st0, bv, sv_relu(4));
+  bias_load<8>(a.w.p[13], lane, bv);
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + L256, sL5 + 2 * L256, lane, B, A, st0, bv, sv_relu(5));
+  bias_load<8>(a.w.p[15], lane, bv);
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + 2 * L256, wp + seg_off4(SEG_PI), lane, A, B, st0, bv, sv_relu(6));
+  // ---- sigma head on h7 = relu(B) (VALU): sigma = |w_sigma . h7 + b|  (nerf.py:94, 115)
   {
     const float* ws = a.w.p[W_SIGMA] + 4 * h;
     float s = 0.f;
@@ -187,20 +213,21 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 wq = *reinterpret_cast<const float4*>(ws + 32 * t + 8 * g);
-        s = __builtin_fmaf(act[t][4 * g + 0], wq.x, s);
-        s = __builtin_fmaf(act[t][4 * g + 1], wq.y, s);
-        s = __builtin_fmaf(act[t][4 * g + 2], wq.z, s);
-        s = __builtin_fmaf(act[t][4 * g + 3], wq.w, s);
+        s = __builtin_fmaf(fmaxf(B[t][4 * g + 0], 0.f), wq.x, s);
+        s = __builtin_fmaf(fmaxf(B[t][4 * g + 1], 0.f), wq.y, s);
+        s = __builtin_fmaf(fmaxf(B[t][4 * g + 2], 0.f), wq.z, s);
+        s = __builtin_fmaf(fmaxf(B[t][4 * g + 3], 0.f), wq.w, s);
       }
     s += __shfl_xor(s, 32);
-    if (valid && h == 0) a.sigma[m] = fabsf(s + a.w.p[B_SIGMA][0]);
+    if (valid && h == 0) {
+      const float pre = s + a.w.p[B_SIGMA][0];
+      a.sigma[m] = fabsf(pre);
+      if (SAVE) a.spre[a.row0 + m] = pre;
+    }
   }
   // ---- point_info: 256 -> 256, no activation; next segment = dir_info (4 tiles)
   bias_load<8>(a.w.p[B_PI], lane, bv);
-  reg_layer<32, 8, 32, 4, true>(wp + seg_off4(SEG_PI), wp + seg_off4(SEG_DIR), lane, act, acc, st0);
-  add_bias<8>(bv, lane, acc);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) act[t] = acc[t];
+  reg_layer<32, 8, 32, 4, true, true, SAVE>(wp + seg_off4(SEG_PI), wp + seg_off4(SEG_DIR), lane, B, A, st0, bv, sv_relu(7));
   // ---- dir_info: cat(gamma_d, feat) -> 128, ReLU.  gamma_d part + bias = dvec (per ray), the accumulator start
   {
     const float* dv = a.dvec + (size_t)ray * HALF + 4 * h;
@@ -209,13 +236,13 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 q = *reinterpret_cast<const float4*>(dv + 32 * f + 8 * g);
-        acc[f][4 * g + 0] = q.x;
-        acc[f][4 * g + 1] = q.y;
-        acc[f][4 * g + 2] = q.z;
-        acc[f][4 * g + 3] = q.w;
+        B[f][4 * g + 0] = q.x;
+        B[f][4 * g + 1] = q.y;
+        B[f][4 * g + 2] = q.z;
+        B[f][4 * g + 3] = q.w;
       }
   }
-  reg_layer<32, 4, 32, 4, false>(wp + seg_off4(SEG_DIR), nullptr, lane, act, acc, st0);
+  reg_layer<32, 4, 32, 4, false, false, SAVE>(wp + seg_off4(SEG_DIR), nullptr, lane, A, B, st0, nullptr, sv_rows(S_FEAT));
   // ---- colour head (VALU): rgb = sigmoid(W_c relu(.) + b)  (nerf.py:99, 119)
   {
     const float* wc = a.w.p[W_COLOR] + 4 * h;
@@ -227,8 +254,9 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
         const float4 q0 = *reinterpret_cast<const float4*>(wc + 32 * t + 8 * g);
         const float4 q1 = *reinterpret_cast<const float4*>(wc + HALF + 32 * t + 8 * g);
         const float4 q2 = *reinterpret_cast<const float4*>(wc + 2 * HALF + 32 * t + 8 * g);
-        const float c0 = fmaxf(acc[t][4 * g + 0], 0.f), c1 = fmaxf(acc[t][4 * g + 1], 0.f);
-        const float c2 = fmaxf(acc[t][4 * g + 2], 0.f), c3 = fmaxf(acc[t][4 * g + 3], 0.f);
+        const float c0 = fmaxf(B[t][4 * g + 0], 0.f), c1 = fmaxf(B[t][4 * g + 1], 0.f);
+        const float c2 = fmaxf(B[t][4 * g + 2], 0.f), c3 = fmaxf(B[t][4 * g + 3], 0.f);
+        if (SAVE && valid) *reinterpret_cast<float4*>(srow + S_C * MS + 32 * t + 8 * g) = make_float4(c0, c1, c2, c3);
         z0 = __builtin_fmaf(c3, q0.w, __builtin_fmaf(c2, q0.z, __builtin_fmaf(c1, q0.y, __builtin_fmaf(c0, q0.x, z0))));
         z1 = __builtin_fmaf(c3, q1.w, __builtin_fmaf(c2, q1.z, __builtin_fmaf(c1, q1.y, __builtin_fmaf(c0, q1.x, z1))));
         z2 = __builtin_fmaf(c3, q2.w, __builtin_fmaf(c2, q2.z, __builtin_fmaf(c1, q2.y, __builtin_fmaf(c0, q2.x, z2))));
@@ -245,9 +273,12 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   }
 }
 
-hipError_t launch_field_fwd_reg(const FieldArgs& a, hipStream_t st) {
+hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st) {
   const int tiles = (a.M + RM - 1) / RM;
-  hipLaunchKernelGGL(k_field_fwd_reg, dim3(tiles), dim3(64), 0, st, a);
+  if (save)
+    hipLaunchKernelGGL(k_field_fwd_reg<true>, dim3(tiles), dim3(64), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_field_fwd_reg<false>, dim3(tiles), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

@@ -78,7 +78,7 @@ struct MergeArgs {
 
 hipError_t launch_pack_weights(const Weights24& w, float4* out, int nseg, hipStream_t st);
 hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
-hipError_t launch_field_fwd_reg(const FieldArgs& a, hipStream_t st);
+hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
 hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st);
 size_t merge_lds_bytes(int P);

@@ -75,7 +75,7 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, model, need_grad, row, col, pb, K9, ray0, *params):
         B = row.shape[0]
         Nc, Nf = model.num_coarse, model.num_fine
-        flags = _abi.SAVE_FOR_BACKWARD if need_grad else 0
+        flags = (_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
         ws = model._workspace(B, flags)
         dev = row.device
         C_c = torch.empty(B, 3, dtype=torch.float32, device=dev)
@@ -122,6 +122,8 @@ class NeRFModel(nn.Module):
         self.check_resample = False
         #: (near, far) of the GLOBAL ray 0 when one batch is sharded over several GPUs (quirk Q6); None = local ray 0
         self.ray0_near_far = None
+        #: use the LDS-tile field kernels instead of the register-resident ones (A/B measurements, tests)
+        self.force_tile_kernel = False
         self._ws = {}
         self._ws_generation = 0
 
