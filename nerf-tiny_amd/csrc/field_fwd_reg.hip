@@ -68,6 +68,12 @@ __device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const 
   auto activate = [&](int t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) tin[t & 1][r] = RELU_IN ? fmaxf(prev[t][r], 0.f) : prev[t][r];
+    if (!SAVE) {
+      // pin the activated tile to this program point (the training variant's stores do that implicitly); without it
+      // the compiler hoists every tile's ReLU to the top of the layer and spills ~370 registers
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));
+    }
     if (SAVE && sv.rows != nullptr && sv.live) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -117,7 +123,7 @@ __device__ __forceinline__ void bias_load(const float* __restrict__ bias, int la
   for (int f = 0; f < NFT; ++f) bv[f] = bias[f * 32 + (lane & 31)];
 }
 
-template <bool SAVE>
+template <bool SAVE, bool DEBUG>
 __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * RM;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   // gp[t][4g + s] = gamma_p[k], k = 32t + 8g + 4h + s  (4 consecutive k = two (sin, cos) pairs)
   float p[3];
   sample_point(rf, a.t[mc], p);
-  if (a.pts_dbg && valid && h == 0) {
+  if (DEBUG && a.pts_dbg && valid && h == 0) {
     a.pts_dbg[(size_t)m * 3 + 0] = p[0];
     a.pts_dbg[(size_t)m * 3 + 1] = p[1];
     a.pts_dbg[(size_t)m * 3 + 2] = p[2];
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
       gp[g8 >> 2][4 * (g8 & 3) + 2 * e + 1] = cv;
     }
   }
-  if (a.gp_dbg && valid) {
+  if (DEBUG && a.gp_dbg && valid) {
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8)
 #pragma unroll
@@ -276,9 +282,11 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st) {
   const int tiles = (a.M + RM - 1) / RM;
   if (save)
-    hipLaunchKernelGGL(k_field_fwd_reg<true>, dim3(tiles), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_field_fwd_reg<true, false>), dim3(tiles), dim3(64), 0, st, a);
+  else if (a.pts_dbg || a.gp_dbg)
+    hipLaunchKernelGGL((k_field_fwd_reg<false, true>), dim3(tiles), dim3(64), 0, st, a);
   else
-    hipLaunchKernelGGL(k_field_fwd_reg<false>, dim3(tiles), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_field_fwd_reg<false, false>), dim3(tiles), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 
