@@ -309,7 +309,8 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   fb.t = at<float>(ws, L.t_f); fb.rgb = at<float>(ws, L.rgb_f);
   fb.drgb = at<float>(ws, L.drgb_f); fb.dsig = at<float>(ws, L.dsig_f); fb.dt = at<float>(ws, L.dt_f);
   fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf;
-  { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st); HIP_TRY(launch_field_bwd(fb, true, st)); }
+  const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
+  { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st); HIP_TRY(tile_kernel ? launch_field_bwd(fb, true, st) : launch_field_bwd_reg(fb, true, st)); }
 
   // 3. resampling + coarse composite backward (nerf.py:225-261, 263-281)
   CoarseBwdArgs cb;
@@ -326,7 +327,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   fb.t = at<float>(ws, L.t_c); fb.rgb = at<float>(ws, L.rgb_c);
   fb.drgb = at<float>(ws, L.drgb_c); fb.dsig = at<float>(ws, L.dsig_c); fb.dt = nullptr;
   fb.row0 = 0; fb.tile0 = 0; fb.N = Nc; fb.M = B * Nc;
-  { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st); HIP_TRY(launch_field_bwd(fb, false, st)); }
+  { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st); HIP_TRY(tile_kernel ? launch_field_bwd(fb, false, st) : launch_field_bwd_reg(fb, false, st)); }
 
   // 5. weight gradients: dW = G^T X over all B*(Nc+Nf) samples
   {

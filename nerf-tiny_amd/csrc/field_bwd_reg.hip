@@ -1,0 +1,232 @@
+// field_bwd_reg.hip -- the backward dX chain with REGISTER-RESIDENT gradients (MI355X / gfx950).
+//
+// Same arithmetic and the same packed (transposed) weight image as k_field_bwd (field_bwd.hip), organised like
+// k_field_fwd_reg: one wave owns 32 samples and all 256 features; the raw accumulators of one layer, masked by the
+// forward pass's ReLU bits, ARE the B operand of the next (transposed) layer, so there is no LDS and no barrier.
+// Every layer's pre-activation gradient is streamed to the row-major G buffers by its CONSUMER, one 16-byte group per
+// lane and k-block tile, interleaved with the MFMA stream (the weight-gradient GEMMs read G afterwards).
+// FINE additionally carries d loss/d gamma_p (skip layer + layer 0) -> d loss/d point -> d loss/d t_fine (quirk Q9).
+#include "field_common.h"
+
+namespace nerf {
+
+constexpr int RMB = 32;  // samples per wave
+
+template <int NFT>
+struct WStageB {
+  float4 w[NFT];
+};
+
+__device__ __forceinline__ float f4cb(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// acc[f] (+)= sum_k Wt[f-tile][k] * in[k], in = prev tile values (MASK_IN: zeroed where the forward activation was not > 0;
+// mb[t] = mask word of input tile t).  grow != nullptr: the activated input (= this layer's pre-activation gradient) is
+// stored to G rows.  Two fragment stages as in k_field_fwd_reg; st0 = k-block 0 on entry / next segment's k-block 0 on exit.
+template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT, bool MASK_IN>
+__device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
+                                              const f32x16* prev, f32x16* acc, WStageB<8>& st0, const unsigned* mb,
+                                              float* __restrict__ grow, bool live) {
+  constexpr int KT = KB / 4;
+  const float4* sl = seg + lane;
+  const float4* nl = next_seg + lane;
+  WStageB<8> st1;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 tin[2];
+  auto activate = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tin[t & 1][r] = MASK_IN ? (((mb[t] >> r) & 1u) ? prev[t][r] : 0.f) : prev[t][r];
+    if (grow != nullptr) {
+      if (live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) =
+              make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));  // pin (see k_field_fwd_reg)
+    }
+  };
+  activate(0);
+  // one k-block: request the fragments of k-block kb+1 (or of the next segment) into `ld`, multiply with `cur`
+  auto kblock = [&](int kb, const WStageB<8>& cur, WStageB<8>& ld) {
+    if (kb + 1 < KB) {
+#pragma unroll
+      for (int f = 0; f < NFT; ++f) ld.w[f] = sl[(size_t)(f * KB + kb + 1) * 64];
+    } else if (next_seg != nullptr) {
+#pragma unroll
+      for (int f = 0; f < NNFT; ++f) ld.w[f] = nl[(size_t)(f * NKB) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((kb & 3) == 2 && (kb >> 2) + 1 < KT) activate((kb >> 2) + 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float b = tin[(kb >> 2) & 1][4 * (kb & 3) + s];
+#pragma unroll
+      for (int f = 0; f < NFT; ++f) {
+        if (ZERO_INIT && kb == 0 && s == 0)
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4cb(cur.w[f], s), b, zero, 0, 0, 0);
+        else
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4cb(cur.w[f], s), b, acc[f], 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int kb = 0; kb < KB; kb += 2) {  // KB is even for every segment
+    kblock(kb, st0, st1);
+    kblock(kb + 1, st1, st0);
+  }
+}
+
+template <bool FINE>
+__global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
+  const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * RMB;
+  const int m = m0 + j;
+  const bool valid = m < a.M;
+  const int mc = valid ? m : a.M - 1;
+  const size_t MS = (size_t)a.Mtot * WIDTH;
+  const size_t grow_off = (size_t)(a.row0 + mc) * WIDTH + 4 * h;  // this lane's 16-byte groups start here
+  float* const grow = a.G + grow_off;
+  const float* const srow = a.save + grow_off;
+  const uint16_t* const mrow = a.masks + ((size_t)(a.tile0 + (m0 >> 6)) * 4 + ((m0 >> 5) & 1)) * 256 + h * 32 + j;
+  const size_t MKS = (size_t)a.tiles_tot * 4 * 256;
+  const float4* wp = a.wp;
+  constexpr int L256 = 8 * 32 * 64;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  WStageB<8> st0;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) st0.w[f] = (wp + seg_off4(SEG_T_DIR) + lane)[(size_t)(f * 16) * 64];
+
+  auto load_masks = [&](int layer, unsigned (&mb)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) mb[t] = mrow[(size_t)layer * MKS + ((t & 1) * 2) * 256 + (t >> 1) * 64];
+  };
+
+  // ---- colour head backward (VALU): rgb = sigmoid(z), z = W_c c + b, c = relu(pre_d)  ->  dpre_d in registers
+  f32x16 D0[4];
+  {
+    float dz[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float o = a.rgb[(size_t)mc * 3 + ch];
+      dz[ch] = valid ? a.drgb[(size_t)mc * 3 + ch] * ((1.0f - o) * o) : 0.f;
+    }
+    if (valid && h == 0) *reinterpret_cast<float4*>(a.dz + (size_t)(a.row0 + m) * 4) = make_float4(dz[0], dz[1], dz[2], 0.f);
+    const float* wc = a.w.p[W_COLOR] + 4 * h;
+    const float* crow = srow + S_C * MS;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 cv = *reinterpret_cast<const float4*>(crow + 32 * t + 8 * g);
+        const float4 q0 = *reinterpret_cast<const float4*>(wc + 32 * t + 8 * g);
+        const float4 q1 = *reinterpret_cast<const float4*>(wc + HALF + 32 * t + 8 * g);
+        const float4 q2 = *reinterpret_cast<const float4*>(wc + 2 * HALF + 32 * t + 8 * g);
+        D0[t][4 * g + 0] = cv.x > 0.f ? __builtin_fmaf(q2.x, dz[2], __builtin_fmaf(q1.x, dz[1], q0.x * dz[0])) : 0.f;
+        D0[t][4 * g + 1] = cv.y > 0.f ? __builtin_fmaf(q2.y, dz[2], __builtin_fmaf(q1.y, dz[1], q0.y * dz[0])) : 0.f;
+        D0[t][4 * g + 2] = cv.z > 0.f ? __builtin_fmaf(q2.z, dz[2], __builtin_fmaf(q1.z, dz[1], q0.z * dz[0])) : 0.f;
+        D0[t][4 * g + 3] = cv.w > 0.f ? __builtin_fmaf(q2.w, dz[2], __builtin_fmaf(q1.w, dz[1], q0.w * dz[0])) : 0.f;
+      }
+  }
+  f32x16 A[8], B[8];
+  unsigned mb[8];
+  // ---- dir_info backward: dfeat = W_d[:, 24:]^T dpre_d  (256 <- 128); stores dpre_d
+  reg_layer_bwd<16, 8, 32, 8, true, false>(wp + seg_off4(SEG_T_DIR), wp + seg_off4(SEG_T_PI), lane, D0, A, st0, nullptr,
+                                           grow + G_D * MS, valid);
+  // ---- point_info backward + sigma head: dh7 = W_pi^T dfeat + w_sigma (x) dsigma_pre; stores dfeat
+  {
+    const float sp = a.spre[a.row0 + mc];
+    const float sgn = sp > 0.f ? 1.0f : (sp < 0.f ? -1.0f : 0.f);  // d|x|/dx with sign(0) = 0 like torch
+    const float ds = valid ? a.dsig[mc] * sgn : 0.f;
+    if (valid && h == 0) a.dspre[a.row0 + m] = ds;
+    const float dsb = (h == 0) ? ds : 0.f;  // outer product as one MFMA per tile: A = w_sigma rows, B = ds on lane half 0
+    const float* ws = a.w.p[W_SIGMA];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) B[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[f * 32 + j], dsb, zero, 0, 0, 0);
+  }
+  reg_layer_bwd<32, 8, 32, 8, false, false>(wp + seg_off4(SEG_T_PI), wp + seg_off4(SEG_T_L7), lane, A, B, st0, nullptr,
+                                            grow + G_PI * MS, valid);
+  // ---- layers 7, 6, 5: input = raw d h_l masked by h_l > 0 (= dpre_l, stored), output = raw d h_{l-1}
+  const float4* const sT7 = wp + seg_off4(SEG_T_L7);
+  load_masks(7, mb);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7, sT7 + L256, lane, B, A, st0, mb, grow + 7 * MS, valid);
+  load_masks(6, mb);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + L256, sT7 + 2 * L256, lane, A, B, st0, mb, grow + 6 * MS, valid);
+  load_masks(5, mb);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + 2 * L256, wp + seg_off4(SEG_T_L4A), lane, B, A, st0, mb, grow + 5 * MS, valid);
+  // ---- layer 4 (input cat(h3, gamma_p)): d h3, and for the fine pass d gamma_p through the skip connection
+  f32x16 accg[2];
+  load_masks(4, mb);
+  if (FINE) {
+    reg_layer_bwd<32, 8, 32, 2, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L4B), lane, A, B, st0, mb, grow + 4 * MS, valid);
+    reg_layer_bwd<32, 2, 32, 8, true, true>(wp + seg_off4(SEG_T_L4B), wp + seg_off4(SEG_T_L3), lane, A, accg, st0, mb, nullptr, valid);
+  } else {
+    reg_layer_bwd<32, 8, 32, 8, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L3), lane, A, B, st0, mb, grow + 4 * MS, valid);
+  }
+  // ---- layers 3, 2, 1
+  const float4* const sT3 = wp + seg_off4(SEG_T_L3);
+  load_masks(3, mb);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3, sT3 + L256, lane, B, A, st0, mb, grow + 3 * MS, valid);
+  load_masks(2, mb);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3 + L256, sT3 + 2 * L256, lane, A, B, st0, mb, grow + 2 * MS, valid);
+  load_masks(1, mb);
+  reg_layer_bwd<32, 8, 32, 2, true, true>(sT3 + 2 * L256, FINE ? wp + seg_off4(SEG_T_L0) : nullptr, lane, B, A, st0, mb, grow + 1 * MS, valid);
+  // ---- dpre_0 = d h0 masked; fine: d gamma_p += W_0^T dpre_0
+  load_masks(0, mb);
+  if (FINE) {
+    reg_layer_bwd<32, 2, 32, 2, false, true>(wp + seg_off4(SEG_T_L0), nullptr, lane, A, accg, st0, mb, grow, valid);
+    // gamma -> point -> depth.  accg[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of pair pi = 4(4t+g) + 2h + e
+    const int ray = mc / a.N;
+    const float* rf = a.rayf + (size_t)ray * RAYF;
+    float p[3];
+    sample_point(rf, a.t[mc], p);
+    float dp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int pi = 4 * g8 + 2 * h + e;
+        if (pi < 30) {
+          const int c = pi / 10, l = pi - 10 * c;
+          const float x = (c == 0) ? p[0] : ((c == 1) ? p[1] : p[2]);
+          const float fl = __uint_as_float(kFreqPointBits[l]);
+          float sn, cn;
+          sincos_phase(x * fl, sn, cn);
+          const float dgs = accg[g8 >> 2][4 * (g8 & 3) + 2 * e], dgc = accg[g8 >> 2][4 * (g8 & 3) + 2 * e + 1];
+          const float contrib = fl * (cn * dgs - sn * dgc);
+          if (c == 0) dp[0] += contrib; else if (c == 1) dp[1] += contrib; else dp[2] += contrib;
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dp[c] += __shfl_xor(dp[c], 32);
+    if (valid && h == 0) {
+      const float dtp = __builtin_fmaf(rf[RF_DWRD + 2], dp[2], __builtin_fmaf(rf[RF_DWRD + 1], dp[1], rf[RF_DWRD] * dp[0]));
+      a.dt[m] += dtp;
+    }
+  } else if (valid) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = ((mb[t] >> (4 * g + 0)) & 1u) ? A[t][4 * g + 0] : 0.f;
+        v.y = ((mb[t] >> (4 * g + 1)) & 1u) ? A[t][4 * g + 1] : 0.f;
+        v.z = ((mb[t] >> (4 * g + 2)) & 1u) ? A[t][4 * g + 2] : 0.f;
+        v.w = ((mb[t] >> (4 * g + 3)) & 1u) ? A[t][4 * g + 3] : 0.f;
+        *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) = v;
+      }
+  }
+}
+
+hipError_t launch_field_bwd_reg(const FieldBwdArgs& a, bool fine, hipStream_t st) {
+  const int tiles = (a.M + RMB - 1) / RMB;
+  if (fine)
+    hipLaunchKernelGGL(k_field_bwd_reg<true>, dim3(tiles), dim3(64), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_field_bwd_reg<false>, dim3(tiles), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace nerf

@@ -158,6 +158,7 @@ struct SmallGradArgs {
 };
 
 hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st);
+hipError_t launch_field_bwd_reg(const FieldBwdArgs& a, bool fine, hipStream_t st);
 hipError_t launch_dw(const DwProblem& p, hipStream_t st);
 size_t dw_slab_floats(int nout, int nin);
 size_t dw_slab_floats_max();
