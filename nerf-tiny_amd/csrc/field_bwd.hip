@@ -290,20 +290,26 @@ __device__ __forceinline__ void dw_rows(const DwProblem& p, const float* __restr
   };
   constexpr long long G = 2 * DW_UNROLL;  // rows per stage
   DwStage s0, s1, s2;
+  // branch-free rotation: the two prefetches past the end re-read the last stage (valid memory, never multiplied)
+  const long long r_last = CHECK ? r_end : r_end - G;
+  auto at = [&](long long r) { return (CHECK || r <= r_last) ? r : r_last; };
   load(r_begin, s0);
-  load(r_begin + G, s1);
+  load(at(r_begin + G), s1);
   for (long long r0 = r_begin; r0 < r_end; r0 += 3 * G) {
-    load(r0 + 2 * G, s2);
+    // the scheduling barriers keep each stage's requests where they are written: two stages (64 MFMAs) ahead of
+    // their use -- left alone the compiler sinks them next to the uses and every iteration waits on HBM
+    load(at(r0 + 2 * G), s2);
+    __builtin_amdgcn_sched_barrier(0);
     mul(r0, s0);
-    if (CHECK || r0 + 3 * G < r_end) {
-      load(r0 + 3 * G, s0);
-      mul(r0 + G, s1);
-      load(r0 + 4 * G, s1);
-      mul(r0 + 2 * G, s2);
-    } else {  // last trip of the unchecked loop: nothing left to prefetch
-      mul(r0 + G, s1);
-      mul(r0 + 2 * G, s2);
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    load(at(r0 + 3 * G), s0);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(r0 + G, s1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(at(r0 + 4 * G), s1);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(r0 + 2 * G, s2);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -151,3 +151,60 @@ def test_forward_linearity_property_full_size(oracle, pkg, dev):
     assert torch.equal(torch.cat((a[0], b[0])), Cc)
     assert torch.equal(torch.cat((a[1], b[1])), Cf)
     assert torch.isfinite(Cf).all() and float(Cf.min()) >= 0.0
+
+
+@pytest.mark.parametrize("B,Nc,Nf", [(7, 5, 3), (33, 100, 200), (3, 1024, 1024), (130, 31, 65)])
+def test_ragged_and_maximum_sizes(oracle, pkg, dev, B, Nc, Nf):
+    """sizes that are not multiples of the 32/64-sample tiles, tiles that straddle rays, and the largest Nc/Nf."""
+    row, col, pb, K, _ = oracle.fern_inputs(B, seed=B)
+    w = oracle.make_weights(8, sharp=True)
+    m = pkg.NeRFModel(Nc, Nf, B)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    with torch.no_grad():
+        Cc, Cf = m(row, col, pb, K)
+        oc, of = oracle.render(w, row, col, pb, K, Nc, Nf)
+    assert max_rel(Cc, oc) < TOL and max_rel(Cf, of) < TOL
+
+
+def test_tile_and_register_kernels_agree(oracle, pkg, dev):
+    """the LDS-tile kernels (NERF_HIP_FORCE_TILE_KERNEL) and the register-resident kernels run the same MFMA sequence:
+    forward values to 1e-6, gradients to 1e-5."""
+    B, Nc, Nf = 200, 64, 128
+    row, col, pb, K, Ct = oracle.fern_inputs(B, seed=4)
+    w = oracle.make_weights(9, sharp=True)
+    outs = []
+    for tile in (False, True):
+        m = pkg.NeRFModel(Nc, Nf, B)
+        m.load_state_dict(w)
+        m = m.to(dev)
+        m.force_tile_kernel = tile
+        with torch.no_grad():
+            inf = m(row, col, pb, K)
+        Cc, Cf = m(row, col, pb, K)
+        torch.sum(torch.square(Cc - Ct.to(dev))).backward()
+        outs.append((inf, (Cc.detach(), Cf.detach()), [p.grad.clone() for p in m.network.parameters()]))
+    a, b = outs
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert max_rel(x, y) < 1e-6
+    assert max_rel(a[0][1], a[1][1]) < 1e-6  # inference and training forward agree
+    for x, y in zip(a[2], b[2]):
+        assert float((x - y).norm() / y.norm()) < 1e-5
+
+
+def test_check_resample_raises_like_the_reference_exits(oracle, pkg, dev):
+    """quirk Q7 through the model surface: zero density -> ResampleIndexError when check_resample is on, silent otherwise."""
+    B = 16
+    row, col, pb, K, _ = oracle.lego_inputs(B, seed=0)
+    w = oracle.make_weights(0)
+    w["network.sigma_layer.0.weight"].zero_()
+    w["network.sigma_layer.0.bias"].zero_()
+    m = pkg.NeRFModel(64, 128, B)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    with torch.no_grad():
+        Cc, Cf = m(row, col, pb, K)  # no abort, finite output
+        assert torch.isfinite(Cf).all()
+        m.check_resample = True
+        with pytest.raises(pkg.nerf.ResampleIndexError):
+            m(row, col, pb, K)
