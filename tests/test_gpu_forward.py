@@ -208,3 +208,24 @@ def test_check_resample_raises_like_the_reference_exits(oracle, pkg, dev):
         m.check_resample = True
         with pytest.raises(pkg.nerf.ResampleIndexError):
             m(row, col, pb, K)
+
+
+def test_render_rows_sharded_frame_with_tail(oracle, pkg, dev):
+    """cfg5-style frame rendering: contiguous ray ranges per rank, tail batch padded and cropped (the reference would
+    drop it, nerf.py:442); two 'ranks' rendered one after the other on this GPU cover the frame exactly once."""
+    n, Bm = 1000, 256
+    row, col, pb, K, _ = oracle.lego_inputs(n, seed=12)
+    w = oracle.make_weights(3, sharp=True)
+    m = pkg.NeRFModel(64, 128, Bm)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    out = torch.zeros(n, 3, device=dev)
+    spans = []
+    for rank in range(2):
+        lo, hi, C = pkg.parallel.render_rows_sharded(m, row.to(dev), col.to(dev), pb.to(dev), K, rank, 2, out=out)
+        spans.append((lo, hi))
+        assert C.shape == (hi - lo, 3)
+    assert spans == [(0, 500), (500, 1000)]
+    with torch.no_grad():
+        oc, of = oracle.render(w, row, col, pb, K, 64, 128)
+    assert max_rel(out, of) < TOL
