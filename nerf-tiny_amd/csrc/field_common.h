@@ -166,7 +166,7 @@ __device__ __forceinline__ void sincos_phase(float ph, float& sn, float& cs) {
   const double x = (double)ph;
   const double n = __builtin_rint(x * 0.63661977236758134308);           // 2/pi
   const float r = (float)__builtin_fma(-n, 1.57079632679489661923, x);  // pi/2
-  const int q = (int)n;
+  const int q = (int)((long long)n & 3);  // quadrant (long long: no overflow for any finite fp32 phase)
   const float z = r * r;
   float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
   ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
