@@ -226,7 +226,7 @@ def main():
                        f"ray-batch DP x{world} (one flat SUM all-reduce of 593,924 fp32 gradients per step)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": read_traffic(),
-                         "kernel": "k_field_fwd (average of the coarse- and fine-pass launches)", "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
+                         "kernel": "k_field_fwd_reg (average of the coarse- and fine-pass launches)", "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "flop_per_launch": flop_launch},
             "whole_path_tflops": round(value / world * flop_ray / 1e12, 2),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
