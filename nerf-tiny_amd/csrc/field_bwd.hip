@@ -1,18 +1,19 @@
 // field_bwd.hip -- backward of the fused field query for MI355X (gfx950).
 //
-//  k_field_bwd<FINE>  the dX chain: per 64-sample tile, walks the network backwards with the TRANSPOSED
+//  k_field_bwd<FINE>  the LDS-tile form of the dX chain (A/B reference; the product path is field_bwd_reg.hip): per 64-sample tile, walks the network backwards with the TRANSPOSED
 //                     weights as the MFMA A operand (same LDS/accumulator layout as the forward kernel),
 //                     applies the ReLU masks saved by the forward pass, and streams every layer's
 //                     pre-activation gradient to HBM ([NGRAD][Mtot][256]) for the weight-gradient GEMMs.
 //                     FINE also back-propagates into the encoding inputs: d loss/d gamma_p (skip layer +
 //                     layer 0) -> d loss/d point -> d loss/d t_fine  (the reference does NOT detach t_fine,
 //                     nerf.py:259 -- quirk Q9).
-//  k_dw<CB>           dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM: the reduction
+//  k_dw               dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM: the reduction
 //                     index is the sample, both operands are read straight from their row-major HBM images
-//                     with 16-byte loads (lane l <- columns 4(l&31)..+3 of rows m, m+1), one 128x128 output
-//                     block (256 accumulator VGPRs) per wave, one workgroup per CU, per-wave partial slabs
-//                     summed by k_dw_reduce (deterministic; no float atomics).  Bias gradients (column sums
-//                     of G) ride along on the VALU.
+//                     (lane l <- columns 4(l&31)..+3 of G and 2(l&31)..+1 of X, rows m, m+1), one 128 x 64 output
+//                     block (128 accumulator VGPRs) per wave, 8 waves, one workgroup per CU, a branch-free
+//                     3-stage register rotation with pinned prefetches, per-wave partial slabs summed by
+//                     k_dw_reduce (deterministic; no float atomics).  Bias gradients (column sums of G) ride
+//                     along on the VALU.
 //  k_small_*          the thin heads: colour (3x128), sigma (1x256), direction encoding part of dir_info.
 //
 // Autograd spans replaced: backward of Network.forward (nerf.py:101-124), Encoder.forward (nerf.py:135-167)

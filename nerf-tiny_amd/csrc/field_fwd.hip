@@ -1,4 +1,5 @@
-// field_fwd.hip -- fused field query for MI355X (gfx950): sample point -> positional encoding ->
+// field_fwd.hip -- weight packing + the LDS-tile form of the fused field query for MI355X (gfx950) (A/B reference,
+// NERF_HIP_FORCE_TILE_KERNEL; the product path is the register-resident form in field_fwd_reg.hip): sample point -> positional encoding ->
 // 8x256 MLP (+ sigma / feature / direction / colour heads) for a tile of 64 samples per workgroup.
 //
 // Replaces, per sample: nerf.py:200-216 (world point), Encoder.forward nerf.py:135-167,
