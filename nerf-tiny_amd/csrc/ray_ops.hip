@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void k_coarse(const CoarseArgs a) {
 // Ties are broken by original index (a stable sort); indices are kept for the backward pass.
 // ---------------------------------------------------------------------------------------------
 
+template <bool WITH_IDX>  // WITH_IDX: carry the original index (stable order + permutation for backward)
 __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int P = a.P, N = a.Nc + a.Nf;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
       val[c * P + i] = v[c];
-      idx[c * P + i] = (uint16_t)i;
+      if (WITH_IDX) idx[c * P + i] = (uint16_t)i;
     }
   }
   __syncthreads();
@@ -246,11 +247,18 @@ __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
           const float x = val[c * P + i], y = val[c * P + l];
-          const uint16_t xi = idx[c * P + i], yi = idx[c * P + l];
-          const bool gt = (x > y) || (x == y && xi > yi);
-          if (gt == asc) {
-            val[c * P + i] = y; val[c * P + l] = x;
-            idx[c * P + i] = yi; idx[c * P + l] = xi;
+          if (WITH_IDX) {
+            const uint16_t xi = idx[c * P + i], yi = idx[c * P + l];
+            const bool gt = (x > y) || (x == y && xi > yi);
+            if (gt == asc) {
+              val[c * P + i] = y; val[c * P + l] = x;
+              idx[c * P + i] = yi; idx[c * P + l] = xi;
+            }
+          } else {  // values only: equal keys are interchangeable
+            const bool gt = x > y;
+            if (gt == asc && x != y) {
+              val[c * P + i] = y; val[c * P + l] = x;
+            }
           }
         }
       }
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
         float* o = a.bundle + gi * 5;
         o[0] = ti; o[1] = r; o[2] = g; o[3] = b; o[4] = sg;
       }
-      if (a.perm) {
+      if (WITH_IDX && a.perm) {
 #pragma unroll
         for (int c = 0; c < 5; ++c) a.perm[((size_t)ray * 5 + c) * N + i] = idx[c * P + i];
       }
@@ -333,8 +341,13 @@ hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st) {
 size_t merge_lds_bytes(int P) { return (size_t)5 * P * (sizeof(float) + sizeof(uint16_t)); }
 hipError_t launch_merge(const MergeArgs& a, hipStream_t st) {
   const size_t lds = merge_lds_bytes(a.P);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_merge, dim3(a.B), dim3(64), lds, st, a);
+  if (a.perm) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_merge<true>, dim3(a.B), dim3(64), lds, st, a);
+  } else {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_merge<false>, dim3(a.B), dim3(64), lds, st, a);
+  }
   return hipGetLastError();
 }
 hipError_t launch_ray_loss(const float* Cc, const float* Cf, const float* Ct, int B, float* loss, float* dCc, float* dCf, hipStream_t st) {
