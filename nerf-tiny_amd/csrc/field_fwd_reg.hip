@@ -123,8 +123,25 @@ __device__ __forceinline__ void bias_load(const float* __restrict__ bias, int la
   for (int f = 0; f < NFT; ++f) bv[f] = bias[f * 32 + (lane & 31)];
 }
 
+#ifdef NERF_STAMPS  // diagnostic build only (make stamps): cycle sums per phase, see scripts/phase_stamps.py
+#define RSTAMP(slot)                                            \
+  do {                                                          \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    const unsigned long long t_ = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    tsum[slot] += t_ - tlast;                                   \
+    tlast = t_;                                                 \
+  } while (0)
+#else
+#define RSTAMP(slot) do { } while (0)
+#endif
+
 template <bool SAVE, bool DEBUG>
 __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
+#ifdef NERF_STAMPS
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
   const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * RM;
   const int m = m0 + j;
@@ -182,6 +199,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   auto sv_rows = [&](int tensor) { return SaveIn{SAVE ? srow + (size_t)tensor * MS : nullptr, nullptr, valid}; };
   auto sv_relu = [&](int layer) { return SaveIn{SAVE ? srow + (size_t)layer * MS : nullptr, SAVE ? mrow + (size_t)layer * MKS : nullptr, valid}; };
 
+  RSTAMP(0);  // prologue: ray / depth loads, sample point, positional encoding
   // two accumulator sets ping-pong: a layer reads the previous layer's raw accumulators (ReLU applied lazily)
   f32x16 A[8], B[8];
   constexpr int L256 = 8 * 32 * 64;  // float4 per 256x256 segment
@@ -210,6 +228,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + L256, sL5 + 2 * L256, lane, B, A, st0, bv, sv_relu(5));
   bias_load<8>(a.w.p[15], lane, bv);
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + 2 * L256, wp + seg_off4(SEG_PI), lane, A, B, st0, bv, sv_relu(6));
+  RSTAMP(1);  // layers 0..7 (8,320 MFMAs = 532,480 cycles at the issue rate)
   // ---- sigma head on h7 = relu(B) (VALU): sigma = |w_sigma . h7 + b|  (nerf.py:94, 115)
   {
     const float* ws = a.w.p[W_SIGMA] + 4 * h;
@@ -231,6 +250,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
       if (SAVE) a.spre[a.row0 + m] = pre;
     }
   }
+  RSTAMP(2);  // sigma head
   // ---- point_info: 256 -> 256, no activation; next segment = dir_info (4 tiles)
   bias_load<8>(a.w.p[B_PI], lane, bv);
   reg_layer<32, 8, 32, 4, true, true, SAVE>(wp + seg_off4(SEG_PI), wp + seg_off4(SEG_DIR), lane, B, A, st0, bv, sv_relu(7));
@@ -249,6 +269,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
       }
   }
   reg_layer<32, 4, 32, 4, false, false, SAVE>(wp + seg_off4(SEG_DIR), nullptr, lane, A, B, st0, nullptr, sv_rows(S_FEAT));
+  RSTAMP(3);  // point_info + dir_info (1,544 MFMAs = 98,816 cycles)
   // ---- colour head (VALU): rgb = sigmoid(W_c relu(.) + b)  (nerf.py:99, 119)
   {
     const float* wc = a.w.p[W_COLOR] + 4 * h;
@@ -277,6 +298,13 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
       a.rgb[(size_t)m * 3 + 2] = 1.0f / (1.0f + expf(-(z2 + bc[2])));
     }
   }
+#ifdef NERF_STAMPS
+  RSTAMP(4);  // colour head + stores
+  if (a.stamps && lane == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(a.stamps + i, tsum[i]);
+    atomicAdd(a.stamps + 7, 1ull);
+  }
+#endif
 }
 
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st) {
