@@ -146,6 +146,34 @@ def synthetic_scene(n_pic=8, H=64, W=64, seed=0):
     return ArrayDataset(imgs, np.stack(rows))
 
 
+def analytic_sphere_scene(n_pic=24, H=64, W=64, seed=5, device="cuda:0"):
+    """A multi-view-CONSISTENT synthetic scene: a unit sphere at the origin (position-coloured, Lambert-shaded) in front of
+    a white background, seen by the ring of cameras of ``synthetic_scene``.  The rays come from ``nerf_hip_rays``, i.e. the
+    reference's camera convention incl. quirk Q2.  Returns an ArrayDataset."""
+    from . import ops
+
+    base = synthetic_scene(n_pic=n_pic, H=H, W=W, seed=seed)
+    poses = base.poses_bounds
+    K_inv = torch.tensor([[1.0, 0.0, -0.5 * W], [0.0, -1.0, 0.5 * H], [0.0, 0.0, -base.focal]]).float().t()
+    imgs = torch.ones(n_pic, H, W, 3)
+    rr, cc = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    row, col = rr.reshape(-1).to(device), cc.reshape(-1).to(device)
+    light = torch.tensor([0.5, 0.3, 0.8]).double()
+    light = light / light.norm()
+    for i in range(n_pic):
+        pb = torch.from_numpy(np.tile(poses[i], (H * W, 1))).float().to(device)
+        _, d_wrd, _ = ops.rays(row, col, pb, K_inv, 2)
+        d = d_wrd.cpu().double()
+        o = torch.from_numpy(poses[i, :15].reshape(3, 5)[:, 3].copy()).double()
+        b = (d * o).sum(1)
+        disc = b * b - ((o * o).sum() - 1.0)
+        t = -b - torch.sqrt(disc.clamp_min(0))
+        p = o + t[:, None] * d
+        colour = (0.5 + 0.5 * p) * (p * light).sum(1).clamp_min(0.15)[:, None]
+        imgs[i] = torch.where((disc > 0)[:, None], colour, torch.ones_like(colour)).float().reshape(H, W, 3)
+    return ArrayDataset(imgs, poses)
+
+
 class DeviceRays:
     """GPU-resident ray sampler (row f1).  ``for row, col, pix_val, poses_bound, pic in rays.epoch(B)`` yields what the
     reference's ``DataLoader(shuffle=True, drop_last=True)`` yields (nerf.py:424, 458) -- but as device tensors produced

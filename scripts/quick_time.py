@@ -1,15 +1,16 @@
 """Quick forward timing on the GPU box (development aid; bench.py is the contract)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import torch
-import nerf_oracle as O
+import bench
 import nerf_tiny_amd as P
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda:0")
-row, col, pb, K, Ct = O.lego_inputs(B, seed=0)
-m = P.NeRFModel(64, 128, B); m.load_state_dict(O.make_weights(0)); m = m.to(dev)
+bench.B = B
+row, col, pb, K, Ct = bench.synth_inputs(0)
+m = bench.synth_weights(0).to(dev)
 row, col, pb = row.to(dev), col.to(dev), pb.float().to(dev)
 with torch.no_grad():
     for _ in range(3): m(row, col, pb, K)

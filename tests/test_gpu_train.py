@@ -78,3 +78,29 @@ def test_runner_trains_checkpoints_and_renders(pkg, dev, tmp_path):
         assert torch.equal(p, q)
     assert abs(run2.optimizer.param_groups[0]["lr"] - 3e-3 * 0.1 ** (40 / 10000)) < 1e-9
     assert run2.trainer("train") == 44
+
+
+def test_parity_on_trained_weights(oracle, pkg, dev):
+    """Parity on weights that come out of TRAINING (not random init): 300 trainer iterations on the multi-view
+    consistent analytic scene, then the HIP forward against the oracle on held-out rays with those weights."""
+    from conftest import max_rel
+
+    scene = pkg.data.analytic_sphere_scene(n_pic=12, H=32, W=32, seed=5, device=dev)
+    run = pkg.NeRFRunner(gpu=0, img_dir="", results_path="/tmp/nerf_ts/", ckpt_path="/tmp/nerf_ts/ck/", low_res=1, total_iter=300,
+                         batch_ray=2048, learning=3e-4, lr_gamma=0.1, lr_milestone=[10, 200], n_coarse=64, n_fine=128,
+                         data_type="sync", step=10 ** 9, decay_end=10000, sched="EXP", continue_=False,
+                         datasets={"train": scene, "val": scene, "test": scene}, log_every=10 ** 9)
+    run.trainer("train")
+    w = {k: v.detach().cpu().clone() for k, v in run.model.state_dict().items()}
+    B = 512
+    idx = torch.randperm(len(scene), generator=torch.Generator().manual_seed(0))[:B]
+    row, col, pix, pb, pic = run.disp_rays.gather(idx.to(dev))
+    m = pkg.NeRFModel(64, 128, B)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    with torch.no_grad():
+        Cc, Cf = m(row, col, pb, run.K_inv)
+        oc, of = oracle.render(w, row.cpu(), col.cpu(), pb.cpu().double(), run.K_inv, 64, 128)
+    ec, ef = max_rel(Cc, oc), max_rel(Cf, of)
+    print(f"trained weights: max-rel C_coarse {ec:.2e} C_fine {ef:.2e}")
+    assert ec < 1e-4 and ef < 1e-4

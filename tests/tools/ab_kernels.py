@@ -1,6 +1,6 @@
 """A/B: register-resident vs LDS-tile field kernels on the same inputs (forward values and gradients)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 import nerf_oracle as O
