@@ -52,6 +52,10 @@ enum {
   NERF_HIP_SAVE_FOR_BACKWARD = 1 << 0, /* forward keeps activations in the workspace for nerf_hip_backward */
   NERF_HIP_FORCE_TILE_KERNEL = 1 << 1, /* inference: use the LDS-tile field kernel instead of the register-resident one
                                           (same results up to summation order; for A/B measurements and tests) */
+  NERF_HIP_BF16_MLP = 1 << 2,          /* BASELINE.json cfg3 "bf16 MLP / fp32 composite": the 12 linear layers of the field MLP
+                                          run on bf16 MFMA (bf16-rounded weights and layer inputs, fp32 accumulation and
+                                          biases); rays, encodings, compositing, resampling and sort stay fp32.  NOT within
+                                          1e-4 of the fp32 reference (about 1e-2); off by default */
 };
 
 /* status word bits (nerf_hip_read_status) */
@@ -149,6 +153,12 @@ int nerf_hip_gather_rays(const int64_t* index, const float* pixels, const float*
 /* Ray generation (nerf.py:52-67, 186-197, 211, 288): per ray d_cam[B,3], d_wrd[B,3], t_coarse[B,Nc]. */
 int nerf_hip_rays(const int64_t* row, const int64_t* col, const float* poses_bound, const float* K_inv9,
                   int B, int Nc, float* d_cam, float* d_wrd, float* t_coarse, void* stream);
+
+/* The field query below with the bf16 MLP of NERF_HIP_BF16_MLP (no debug outputs).
+ * ws: >= nerf_hip_ws_bytes(B, N, N, NERF_HIP_BF16_MLP). */
+int nerf_hip_field_bf16(const float* const* weights24, const int64_t* row, const int64_t* col,
+                        const float* poses_bound, const float* K_inv9, const float* t, int B, int N,
+                        float* rgb, float* sigma, void* ws, size_t ws_bytes, void* stream);
 
 /* Field query (nerf.py:200-219 + Encoder 135-167 + Network 101-124) at depths t[B,N]:
  * rgb[B,N,3], sigma[B,N]; optional debug outputs pts[B,N,3], gamma_p[B,N,60] (may be NULL).

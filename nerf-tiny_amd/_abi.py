@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("NERF_HIP_LIB", os.path.join(_HERE, "libnerf_hip.so"))
 NERF_HIP_ABI_VERSION = 1
 SAVE_FOR_BACKWARD = 1 << 0
 FORCE_TILE_KERNEL = 1 << 1
+BF16_MLP = 1 << 2
 STATUS_RESAMPLE_INDEX = 1 << 0
 
 _p = C.c_void_p
@@ -32,6 +33,7 @@ _PROTOS = {
     "nerf_hip_gather_rays": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p]),
     "nerf_hip_rays": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p]),
     "nerf_hip_field": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_size_t, _p]),
+    "nerf_hip_field_bf16": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, C.c_size_t, _p]),
     "nerf_hip_coarse_composite": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
     "nerf_hip_coarse_composite_backward": (C.c_int, [_p, _p, _p, _p, C.c_float, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
     "nerf_hip_merge_composite": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, _p]),

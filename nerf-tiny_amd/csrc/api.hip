@@ -8,6 +8,7 @@
 #include <math.h>
 #include <string.h>
 
+#include "bf16_common.h"
 #include "kernels.h"
 
 using namespace nerf;
@@ -52,6 +53,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
   auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
   L.status = take(256);
   L.packed = take((size_t)PACKED_ALL_F4 * 16);
+  if (flags & NERF_HIP_BF16_MLP) L.packed_bf = take(BF_IMAGE_BYTES);
   L.rayf = take(b * RAYF * 4);
   L.dvec = take(b * HALF * 4);
   L.t_c = take(b * Nc * 4);
@@ -168,10 +170,16 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   if (int rc = check_device()) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool save = (flags & NERF_HIP_SAVE_FOR_BACKWARD) != 0;
+  const bool bf16 = (flags & NERF_HIP_BF16_MLP) != 0;
+  if (bf16 && save) return fail(NERF_HIP_ERR_ARG, "NERF_HIP_BF16_MLP: training (SAVE_FOR_BACKWARD) is not available in this build");
   const Weights24 w = as_w24(weights24);
 
   HIP_TRY(hipMemsetAsync(at<void>(ws, L.status), 0, 256, st));
-  { ProfScope ps(NERF_HIP_K_PACK, st); HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st)); }
+  {
+    ProfScope ps(NERF_HIP_K_PACK, st);
+    if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
+    else HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
+  }
 
   RaysArgs ra;
   memset(&ra, 0, sizeof(ra));
@@ -187,6 +195,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.wp = at<float4>(ws, L.packed);
+  if (bf16) fa.wbf = at<unsigned char>(ws, L.packed_bf);
   fa.w = w;
   fa.rayf = at<float>(ws, L.rayf);
   fa.dvec = at<float>(ws, L.dvec);
@@ -204,7 +213,8 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     fa.row0 = 0; fa.tile0 = 0; fa.tiles_tot = tiles_c + tiles_f; fa.Mtot = (long long)B * (Nc + Nf);
   }
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(tile_kernel ? launch_field_fwd(fa, save, st) : launch_field_fwd_reg(fa, save, st)); }
+  auto field = [&](const FieldArgs& f) { return bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
+  { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(field(fa)); }
 
   CoarseArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -223,7 +233,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.sigma = at<float>(ws, L.sig_f);
   fa.N = Nf; fa.M = B * Nf;
   if (save) { fa.row0 = B * Nc; fa.tile0 = tiles_c; }
-  { ProfScope ps(NERF_HIP_K_FIELD_FINE, st); HIP_TRY(tile_kernel ? launch_field_fwd(fa, save, st) : launch_field_fwd_reg(fa, save, st)); }
+  { ProfScope ps(NERF_HIP_K_FIELD_FINE, st); HIP_TRY(field(fa)); }
 
   MergeArgs ma;
   memset(&ma, 0, sizeof(ma));
@@ -278,6 +288,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   if (int rc = check_weights(const_cast<const float* const*>(dweights24))) return rc;
   if (!dC_coarse || !dC_fine || !ws) return fail(NERF_HIP_ERR_ARG, "null argument");
   if (!(flags & NERF_HIP_SAVE_FOR_BACKWARD)) return fail(NERF_HIP_ERR_ARG, "backward needs a forward run with NERF_HIP_SAVE_FOR_BACKWARD");
+  if (flags & NERF_HIP_BF16_MLP) return fail(NERF_HIP_ERR_ARG, "NERF_HIP_BF16_MLP: training is not available in this build");
   const WsLayout L = layout(B, Nc, Nf, flags);
   if (ws_bytes < L.total) return fail(NERF_HIP_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
   if (int rc = check_device()) return rc;
@@ -377,7 +388,7 @@ int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_
   if (int rc = check_sizes(B, Nc, Nf)) return rc;
   const WsLayout L = layout(B, Nc, Nf, flags);
   struct { const char* n; size_t o; } tab[] = {
-      {"status", L.status}, {"packed", L.packed}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
+      {"status", L.status}, {"packed", L.packed}, {"packed_bf", L.packed_bf}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
       {"rgb_c", L.rgb_c}, {"w_c", L.w_c}, {"t_f", L.t_f}, {"sig_f", L.sig_f}, {"rgb_f", L.rgb_f}, {"perm", L.perm},
       {"w_m", L.w_m}, {"bundle", L.bundle}, {"save", L.save}, {"masks", L.masks}, {"spre", L.spre}, {"G", L.G}, {"dz", L.dz},
       {"dspre", L.dspre}, {"drgb_c", L.drgb_c}, {"dsig_c", L.dsig_c}, {"drgb_f", L.drgb_f}, {"dsig_f", L.dsig_f},
@@ -451,6 +462,37 @@ int nerf_hip_field(const float* const* weights24, const int64_t* row, const int6
   fa.t = t; fa.rgb = rgb; fa.sigma = sigma; fa.pts_dbg = pts; fa.gp_dbg = gamma_p;
   fa.N = N; fa.M = B * N;
   HIP_TRY(launch_field_fwd_reg(fa, false, st));
+  return NERF_HIP_OK;
+}
+
+int nerf_hip_field_bf16(const float* const* weights24, const int64_t* row, const int64_t* col, const float* poses_bound,
+                        const float* K_inv9, const float* t, int B, int N, float* rgb, float* sigma, void* ws, size_t ws_bytes,
+                        void* stream) {
+  if (B < 1 || N < 1 || N > 1024) return fail(NERF_HIP_ERR_ARG, "bad sizes");
+  if (int rc = check_weights(weights24)) return rc;
+  if (!row || !col || !poses_bound || !K_inv9 || !t || !rgb || !sigma || !ws) return fail(NERF_HIP_ERR_ARG, "null argument");
+  const int Nl = N < 2 ? 2 : N;
+  const WsLayout L = layout(B < 2 ? 2 : B, Nl, Nl, NERF_HIP_BF16_MLP);
+  if (ws_bytes < L.total) return fail(NERF_HIP_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
+  if (int rc = check_device()) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Weights24 w = as_w24(weights24);
+  HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
+  RaysArgs ra;
+  memset(&ra, 0, sizeof(ra));
+  ra.row = row; ra.col = col; ra.pb = poses_bound;
+  memcpy(ra.K, K_inv9, 9 * sizeof(float));
+  ra.B = B; ra.Nc = Nl;
+  ra.rayf = at<float>(ws, L.rayf);
+  HIP_TRY(launch_rays(ra, st));
+  FieldArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.wbf = at<unsigned char>(ws, L.packed_bf);
+  fa.w = w;
+  fa.rayf = at<float>(ws, L.rayf);
+  fa.t = t; fa.rgb = rgb; fa.sigma = sigma;
+  fa.N = N; fa.M = B * N;
+  HIP_TRY(launch_field_fwd_bf16(fa, false, st));
   return NERF_HIP_OK;
 }
 

@@ -1,0 +1,43 @@
+// bf16_common.h -- layout of the bf16 weight STREAM used by the bf16-MLP variant of the field query (cfg3 of
+// BASELINE.json: "bf16 MLP / fp32 composite").  MI355X / gfx950 only.
+//
+// Arithmetic of the variant (restated by tests/test_gpu_bf16.py's torch emulation): every linear layer of the field
+// MLP (nerf.py:78-99) multiplies bf16-rounded weights with bf16-rounded inputs, accumulates in fp32 starting from the
+// fp32 bias, and hands its (ReLU'd) output to the next layer rounded to bf16 (round-to-nearest-even).  The positional
+// encodings are computed in fp32 exactly as in the fp32 path and rounded to bf16 once.  sigma = |.| and the colour sigmoid are
+// fp32 on the fp32 accumulators; everything outside the MLP (rays, depths, compositing, resampling, sort) stays fp32.
+//
+// The image holds one v_mfma_f32_32x32x16_bf16 A fragment (32 output features x 16 inputs, 8 bf16 = 16 bytes per lane,
+// 1 KiB per wave) per MFMA, in the exact order a wave consumes them: layer by layer, output tile by output tile,
+// k-step by k-step.  Lane (i, h) of fragment (f, ks) holds W[32f + i][k] for the 8 inputs
+//     k = 16ks + 4h + {0,1,2,3} and 16ks + 8 + 4h + {0,1,2,3}
+// which is where the 32x32 fp32 accumulator layout leaves them: lane (sample j, half h) of an accumulator tile holds
+// features 8g + 4h + r of sample j (register 4g + r), so registers 0..7 / 8..15 of tile t, converted pairwise to bf16,
+// ARE the B operands of k-steps 2t / 2t + 1 of the next layer -- no shuffle, no LDS round trip for activations.
+// In front of the fragments sits one 16-KiB block with the fp32 biases per output tile.
+#pragma once
+#include "common.h"
+
+namespace nerf {
+
+constexpr int BF_FRAG_BYTES = 1024;
+constexpr int BF_CHUNK = 16;              // fragments per LDS ring slot (16 KiB)
+constexpr int BF_BIAS_BYTES = 16384;      // bias block (78 tiles x 32 floats used)
+
+// stream segments: first fragment, output tiles, k-steps
+constexpr int BFS_L0 = 0;      // 8 tiles x 4   gamma_p (60 -> 64)
+constexpr int BFS_L1 = 32;     // 8 x 16, likewise L2, L3
+constexpr int BFS_L4 = 416;    // 8 x (16 hidden + 4 gamma_p)   (nerf.py:109: hidden first)
+constexpr int BFS_L5 = 576;    // 8 x 16, likewise L6, L7
+constexpr int BFS_PI = 960;    // 9 x 16: point_info tiles 0..7, tile 8 row 0 = sigma_layer
+constexpr int BFS_DIR = 1104;  // 4 x (2 gamma_d (24 -> 32) + 16 feat)   (nerf.py:117: direction first)
+constexpr int BFS_COL = 1176;  // 1 x 8: rows 0..2 = color_layer
+constexpr int BF_NFRAG = 1184;
+constexpr int BF_NCHUNK = BF_NFRAG / BF_CHUNK;  // 74
+static_assert(BF_NCHUNK * BF_CHUNK == BF_NFRAG, "stream must be whole chunks");
+constexpr size_t BF_IMAGE_BYTES = (size_t)BF_BIAS_BYTES + (size_t)BF_NFRAG * BF_FRAG_BYTES;
+
+// bias tiles (32 floats each) in the bias block
+constexpr int BFB_L0 = 0, BFB_PI = 64, BFB_SIGMA = 72, BFB_DIR = 73, BFB_COL = 77, BF_NBIAS_TILES = 78;
+
+}  // namespace nerf

@@ -9,6 +9,7 @@ constexpr int FIELD_LDS_FLOATS = TM * LDA + 4 * TM * 3;
 
 struct FieldArgs {
   const float4* wp;        // packed weights (PACKED_FWD_F4 float4)
+  const unsigned char* wbf;  // bf16 weight stream (bf16_common.h), bf16-MLP variant only
   Weights24 w;             // raw parameter pointers (biases, sigma / colour heads)
   const float* rayf;       // [B][RAYF]
   const float* dvec;       // [B][128]  b_dir + W_dir[:, :24] * gamma_dir(ray)
@@ -79,6 +80,8 @@ struct MergeArgs {
 hipError_t launch_pack_weights(const Weights24& w, float4* out, int nseg, hipStream_t st);
 hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);
+hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st);
+hipError_t launch_pack_weights_bf16(const Weights24& w, unsigned char* img, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
 hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st);
 size_t merge_lds_bytes(int P);

@@ -75,7 +75,8 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, model, need_grad, row, col, pb, K9, ray0, *params):
         B = row.shape[0]
         Nc, Nf = model.num_coarse, model.num_fine
-        flags = (_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
+        flags = ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
+                 | (_abi.BF16_MLP if model.bf16_mlp else 0))
         ws = model._workspace(B, flags)
         dev = row.device
         C_c = torch.empty(B, 3, dtype=torch.float32, device=dev)
@@ -124,6 +125,8 @@ class NeRFModel(nn.Module):
         self.ray0_near_far = None
         #: use the LDS-tile field kernels instead of the register-resident ones (A/B measurements, tests)
         self.force_tile_kernel = False
+        #: BASELINE.json cfg3: run the MLP on bf16 MFMA (fp32 accumulation, fp32 everything else); ~1e-2 of the fp32 result
+        self.bf16_mlp = False
         self._ws = {}
         self._ws_generation = 0
 

@@ -44,6 +44,20 @@ def field(params, row, col, poses_bound_f32, K_inv, t, debug=False):
     return (rgb, sigma, pts, gp) if debug else (rgb, sigma)
 
 
+def field_bf16(params, row, col, poses_bound_f32, K_inv, t):
+    """field() with the bf16 MLP (NERF_HIP_BF16_MLP) -> rgb[B,N,3], sigma[B,N]"""
+    B, N = t.shape
+    dev = t.device
+    rgb = torch.empty(B, N, 3, device=dev)
+    sigma = torch.empty(B, N, device=dev)
+    n = _abi.ws_bytes(max(B, 2), max(N, 2), max(N, 2), _abi.BF16_MLP)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    _abi.check(_abi.lib().nerf_hip_field_bf16(_abi.ptr_array(params), row.data_ptr(), col.data_ptr(), poses_bound_f32.data_ptr(),
+                                              _k9(K_inv), t.contiguous().data_ptr(), B, N, rgb.data_ptr(), sigma.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _stream(t)))
+    return rgb, sigma
+
+
 def coarse_composite(t_c, sigma_c, rgb_c, near, far, delta0, Nf):
     """-> w_c[B,Nc], C_coarse[B,3], t_f[B,Nf], status(int)"""
     B, Nc = t_c.shape

@@ -166,6 +166,34 @@ def mlp(params, gp: torch.Tensor, gd: torch.Tensor, return_hidden: bool = False)
     return rgb, sigma.squeeze(-1)
 
 
+def _bf16(x: torch.Tensor) -> torch.Tensor:
+    """round-to-nearest-even to bfloat16, returned as fp32 (autograd: straight-through, like a cast)"""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def mlp_bf16(params, gp: torch.Tensor, gd: torch.Tensor, return_hidden: bool = False):
+    """NOT a restatement of the reference (which has no reduced precision): the arithmetic the build's bf16-MLP variant
+    (BASELINE.json cfg3, flag NERF_HIP_BF16_MLP) is specified to perform, emulated in fp32 -- same graph as ``mlp``
+    (nerf.py:101-124) with every linear layer's weights AND inputs rounded to bf16 (RNE), fp32 products/accumulation,
+    fp32 biases and fp32 activations.  Used only to check that variant (tests/test_gpu_bf16.py)."""
+    W = lambda n: _bf16(params[n])
+    b = lambda n: params[n]
+    gp, gd = _bf16(gp), _bf16(gd)
+    h = gp
+    hidden = []
+    for i in range(8):
+        inp = torch.cat((h, gp), dim=-1) if i == 4 else h
+        h = _bf16(torch.relu(F.linear(inp, W(f"network.point_layer.{i}.0.weight"), b(f"network.point_layer.{i}.0.bias"))))
+        hidden.append(h)
+    sigma = torch.abs(F.linear(h, W("network.sigma_layer.0.weight"), b("network.sigma_layer.0.bias")))
+    feat = _bf16(F.linear(h, W("network.point_info.weight"), b("network.point_info.bias")))
+    c = _bf16(torch.relu(F.linear(torch.cat((gd, feat), dim=-1), W("network.dir_info.0.weight"), b("network.dir_info.0.bias"))))
+    rgb = torch.sigmoid(F.linear(c, W("network.color_layer.0.weight"), b("network.color_layer.0.bias")))
+    if return_hidden:
+        return rgb, sigma.squeeze(-1), hidden, feat, c
+    return rgb, sigma.squeeze(-1)
+
+
 def weights_from_sigma(delta: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
     """nerf.py:263-272: s = sigma*delta; T_i = exp(-sum_{j<=i} s_j) (inclusive, quirk Q4); w = T*(1-exp(-s))."""
     s = delta * sigma
@@ -201,9 +229,11 @@ def resample(t_c: torch.Tensor, w_c: torch.Tensor, n_fine: int, check: bool = Tr
     return t_f, dict(cdf=cdf, u=u, k=k, bad=bad)
 
 
-def render(params, row, col, poses_bound, K_inv, n_coarse=64, n_fine=128, last=LAST_DELTA, stages=None, check=True):
+def render(params, row, col, poses_bound, K_inv, n_coarse=64, n_fine=128, last=LAST_DELTA, stages=None, check=True, mlp=None):
     """nerf.py:333-348 + 286-323.  Returns (C_coarse[B,3], C_fine[B,3]).  ``stages`` (a dict) receives
-    every intermediate.  Needs B >= 2 like the reference (quirk Q7: B = 1 breaks .squeeze())."""
+    every intermediate.  Needs B >= 2 like the reference (quirk Q7: B = 1 breaks .squeeze()).
+    ``mlp``: the field network; default = the reference's fp32 ``mlp`` (``mlp_bf16`` for the cfg3 variant)."""
+    mlp = mlp or globals()["mlp"]
     f_p, f_d = frequencies()
     R, o, near, far = poses_extract(poses_bound)
     d_cam = camera_dirs(row, col, K_inv)

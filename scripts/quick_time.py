@@ -12,6 +12,7 @@ bench.B = B
 row, col, pb, K, Ct = bench.synth_inputs(0)
 m = bench.synth_weights(0).to(dev)
 row, col, pb = row.to(dev), col.to(dev), pb.float().to(dev)
+m.bf16_mlp = os.environ.get('BF16') == '1'
 with torch.no_grad():
     for _ in range(3): m(row, col, pb, K)
     torch.cuda.synchronize()
@@ -20,4 +21,10 @@ with torch.no_grad():
     for _ in range(n): m(row, col, pb, K)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+from nerf_tiny_amd import _abi
+_abi.profile_begin(64)
+with torch.no_grad():
+    m(row, col, pb, K)
+torch.cuda.synchronize()
+print({k: round(v[0], 4) for k, v in _abi.profile_end().items()})
 print(f"B={B}: {dt*1e3:.3f} ms/batch  {B/dt:,.0f} rays/s  ({B/dt*227131392/1e12:.1f} TFLOP/s of 157.3)")
