@@ -45,6 +45,9 @@ int check_sizes(int B, int Nc, int Nf) {
   return NERF_HIP_OK;
 }
 
+// wave blocks (32 samples) of one pass of the bf16 kernels: whole 256-sample workgroups
+size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
+
 WsLayout layout(int B, int Nc, int Nf, int flags) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
@@ -69,20 +72,29 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
     L.bundle = take(b * N * 5 * 4);
     const size_t Mtot = b * N;
     const size_t tiles = (b * Nc + TM - 1) / TM + (b * Nf + TM - 1) / TM;
-    L.save = take((size_t)NSAVE * Mtot * WIDTH * 4);
-    L.masks = take((size_t)8 * tiles * 4 * 256 * 2);
     L.spre = take(Mtot * 4);
-    L.G = take((size_t)NGRAD * Mtot * WIDTH * 4);
-    L.dz = take(Mtot * 16);
-    L.dspre = take(Mtot * 4);
+    if (flags & NERF_HIP_BF16_MLP) {
+      const size_t wb = wave_blocks(B, Nc) + wave_blocks(B, Nf);
+      L.packed_bf_bwd = take(BB_IMAGE_BYTES);
+      L.bsave = take(wb * BS_TOTAL_KS * BF_FRAG_BYTES);
+      L.bmask = take(wb * BM_LAYERS * 1024);
+      L.bG = take(wb * BG_TOTAL_KS * BF_FRAG_BYTES);
+      L.bslabs = take(dw_bf16_slab_floats() * 4);
+    } else {
+      L.save = take((size_t)NSAVE * Mtot * WIDTH * 4);
+      L.masks = take((size_t)8 * tiles * 4 * 256 * 2);
+      L.G = take((size_t)NGRAD * Mtot * WIDTH * 4);
+      L.dz = take(Mtot * 16);
+      L.dspre = take(Mtot * 4);
+      L.slabs = take(dw_slab_floats_max() * 4);
+      L.sbuf = take(b * HALF * 4);
+      L.gdbuf = take(b * DIR_DIM * 4);
+    }
     L.drgb_c = take(b * Nc * 12);
     L.dsig_c = take(b * Nc * 4);
     L.drgb_f = take(b * Nf * 12);
     L.dsig_f = take(b * Nf * 4);
     L.dt_f = take(b * Nf * 4);
-    L.slabs = take(dw_slab_floats_max() * 4);
-    L.sbuf = take(b * HALF * 4);
-    L.gdbuf = take(b * DIR_DIM * 4);
   }
   L.total = o;
   return L;
@@ -171,7 +183,6 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool save = (flags & NERF_HIP_SAVE_FOR_BACKWARD) != 0;
   const bool bf16 = (flags & NERF_HIP_BF16_MLP) != 0;
-  if (bf16 && save) return fail(NERF_HIP_ERR_ARG, "NERF_HIP_BF16_MLP: training (SAVE_FOR_BACKWARD) is not available in this build");
   const Weights24 w = as_w24(weights24);
 
   HIP_TRY(hipMemsetAsync(at<void>(ws, L.status), 0, 256, st));
@@ -209,8 +220,14 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
 #endif
   const int tiles_c = (B * Nc + TM - 1) / TM, tiles_f = (B * Nf + TM - 1) / TM;
   if (save) {
-    fa.save = at<float>(ws, L.save); fa.masks = at<uint16_t>(ws, L.masks); fa.spre = at<float>(ws, L.spre);
+    fa.spre = at<float>(ws, L.spre);
     fa.row0 = 0; fa.tile0 = 0; fa.tiles_tot = tiles_c + tiles_f; fa.Mtot = (long long)B * (Nc + Nf);
+    if (bf16) {
+      fa.bsave = at<unsigned char>(ws, L.bsave); fa.bmask = at<uint16_t>(ws, L.bmask);
+      fa.wb0 = 0; fa.wb_tot = (int)(wave_blocks(B, Nc) + wave_blocks(B, Nf));
+    } else {
+      fa.save = at<float>(ws, L.save); fa.masks = at<uint16_t>(ws, L.masks);
+    }
   }
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
   auto field = [&](const FieldArgs& f) { return bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
@@ -232,7 +249,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.rgb = at<float>(ws, L.rgb_f);
   fa.sigma = at<float>(ws, L.sig_f);
   fa.N = Nf; fa.M = B * Nf;
-  if (save) { fa.row0 = B * Nc; fa.tile0 = tiles_c; }
+  if (save) { fa.row0 = B * Nc; fa.tile0 = tiles_c; fa.wb0 = (int)wave_blocks(B, Nc); }
   { ProfScope ps(NERF_HIP_K_FIELD_FINE, st); HIP_TRY(field(fa)); }
 
   MergeArgs ma;
@@ -288,7 +305,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   if (int rc = check_weights(const_cast<const float* const*>(dweights24))) return rc;
   if (!dC_coarse || !dC_fine || !ws) return fail(NERF_HIP_ERR_ARG, "null argument");
   if (!(flags & NERF_HIP_SAVE_FOR_BACKWARD)) return fail(NERF_HIP_ERR_ARG, "backward needs a forward run with NERF_HIP_SAVE_FOR_BACKWARD");
-  if (flags & NERF_HIP_BF16_MLP) return fail(NERF_HIP_ERR_ARG, "NERF_HIP_BF16_MLP: training is not available in this build");
+  const bool bf16 = (flags & NERF_HIP_BF16_MLP) != 0;
   const WsLayout L = layout(B, Nc, Nf, flags);
   if (ws_bytes < L.total) return fail(NERF_HIP_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
   if (int rc = check_device()) return rc;
@@ -300,6 +317,8 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   const int tiles_c = (B * Nc + TM - 1) / TM, tiles_f = (B * Nf + TM - 1) / TM;
   float* save = at<float>(ws, L.save);
   float* G = at<float>(ws, L.G);
+  const int wb_c = (int)wave_blocks(B, Nc), wb_tot = wb_c + (int)wave_blocks(B, Nf);
+  if (bf16) { ProfScope ps(NERF_HIP_K_PACK, st); HIP_TRY(launch_pack_weights_bf16_bwd(w, at<unsigned char>(ws, L.packed_bf_bwd), st)); }
 
   // 1. merged composite + per-channel sort backward (nerf.py:302-321)
   MergeBwdArgs mb;
@@ -314,14 +333,21 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   FieldBwdArgs fb;
   memset(&fb, 0, sizeof(fb));
   fb.wp = at<float4>(ws, L.packed); fb.w = w; fb.rayf = at<float>(ws, L.rayf);
-  fb.save = save; fb.masks = at<uint16_t>(ws, L.masks); fb.spre = at<float>(ws, L.spre);
-  fb.G = G; fb.dz = at<float>(ws, L.dz); fb.dspre = at<float>(ws, L.dspre);
+  fb.spre = at<float>(ws, L.spre);
+  if (bf16) {
+    fb.wbf = at<unsigned char>(ws, L.packed_bf_bwd); fb.bmask = at<uint16_t>(ws, L.bmask); fb.bG = at<unsigned char>(ws, L.bG);
+    fb.wb_tot = wb_tot;
+  } else {
+    fb.save = save; fb.masks = at<uint16_t>(ws, L.masks);
+    fb.G = G; fb.dz = at<float>(ws, L.dz); fb.dspre = at<float>(ws, L.dspre);
+  }
   fb.tiles_tot = tiles_c + tiles_f; fb.Mtot = Mtot;
   fb.t = at<float>(ws, L.t_f); fb.rgb = at<float>(ws, L.rgb_f);
   fb.drgb = at<float>(ws, L.drgb_f); fb.dsig = at<float>(ws, L.dsig_f); fb.dt = at<float>(ws, L.dt_f);
-  fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf;
+  fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf; fb.wb0 = wb_c;
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st); HIP_TRY(tile_kernel ? launch_field_bwd(fb, true, st) : launch_field_bwd_reg(fb, true, st)); }
+  auto chain = [&](const FieldBwdArgs& f, bool fine) { return bf16 ? launch_field_bwd_bf16(f, fine, st) : tile_kernel ? launch_field_bwd(f, fine, st) : launch_field_bwd_reg(f, fine, st); };
+  { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st); HIP_TRY(chain(fb, true)); }
 
   // 3. resampling + coarse composite backward (nerf.py:225-261, 263-281)
   CoarseBwdArgs cb;
@@ -337,11 +363,33 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   // 4. coarse-pass field backward
   fb.t = at<float>(ws, L.t_c); fb.rgb = at<float>(ws, L.rgb_c);
   fb.drgb = at<float>(ws, L.drgb_c); fb.dsig = at<float>(ws, L.dsig_c); fb.dt = nullptr;
-  fb.row0 = 0; fb.tile0 = 0; fb.N = Nc; fb.M = B * Nc;
-  { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st); HIP_TRY(tile_kernel ? launch_field_bwd(fb, false, st) : launch_field_bwd_reg(fb, false, st)); }
+  fb.row0 = 0; fb.tile0 = 0; fb.N = Nc; fb.M = B * Nc; fb.wb0 = 0;
+  { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st); HIP_TRY(chain(fb, false)); }
 
   // 5. weight gradients: dW = G^T X over all B*(Nc+Nf) samples
-  {
+  if (bf16) {
+    ProfScope ps(NERF_HIP_K_BWD_DW, st);
+    const unsigned char* bs = at<unsigned char>(ws, L.bsave);
+    const unsigned char* bg = at<unsigned char>(ws, L.bG);
+    float* slabs = at<float>(ws, L.bslabs);
+    auto X = [&](int t) { return bs + (size_t)wb_tot * bs_cum(t) * BF_FRAG_BYTES; };
+    auto Gt = [&](int t) { return bg + (size_t)wb_tot * bg_cum(t) * BF_FRAG_BYTES; };
+    // layer 0: X = gamma_p
+    HIP_TRY(launch_dw_bf16(Gt(BG_L0), 16, X(BS_GP), 4, wb_tot, slabs, 0, 256, POINT_DIM, dw[0], POINT_DIM, 0, dw[1], st));
+    for (int l = 1; l <= 7; ++l)
+      HIP_TRY(launch_dw_bf16(Gt(BG_L0 + l), 16, X(BS_H0 + l - 1), 16, wb_tot, slabs, 0, 256, WIDTH, dw[2 * l],
+                             (l == 4) ? WIDTH + POINT_DIM : WIDTH, 0, dw[2 * l + 1], st));
+    // layer 4, skip columns
+    HIP_TRY(launch_dw_bf16(Gt(BG_L0 + 4), 16, X(BS_GP), 4, wb_tot, slabs, 0, 256, POINT_DIM, dw[8], WIDTH + POINT_DIM, WIDTH, nullptr, st));
+    // point_info; sigma head = row 3 of the dz/dspre tile against the same h7
+    HIP_TRY(launch_dw_bf16(Gt(BG_PI), 16, X(BS_H0 + 7), 16, wb_tot, slabs, 0, 256, WIDTH, dw[W_PI], WIDTH, 0, dw[B_PI], st));
+    HIP_TRY(launch_dw_bf16(Gt(BG_Z), 2, X(BS_H0 + 7), 16, wb_tot, slabs, 3, 1, WIDTH, dw[W_SIGMA], WIDTH, 0, dw[B_SIGMA], st));
+    // dir_info: feature columns, then direction columns
+    HIP_TRY(launch_dw_bf16(Gt(BG_D), 8, X(BS_FEAT), 16, wb_tot, slabs, 0, HALF, WIDTH, dw[W_DIR], WIDTH + DIR_DIM, DIR_DIM, dw[B_DIR], st));
+    HIP_TRY(launch_dw_bf16(Gt(BG_D), 8, X(BS_GD), 2, wb_tot, slabs, 0, HALF, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, nullptr, st));
+    // colour head = rows 0..2 of the dz/dspre tile against c
+    HIP_TRY(launch_dw_bf16(Gt(BG_Z), 2, X(BS_C), 8, wb_tot, slabs, 0, 3, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR], st));
+  } else {
     ProfScope ps(NERF_HIP_K_BWD_DW, st);
     DwProblem p;
     memset(&p, 0, sizeof(p));
@@ -388,7 +436,7 @@ int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_
   if (int rc = check_sizes(B, Nc, Nf)) return rc;
   const WsLayout L = layout(B, Nc, Nf, flags);
   struct { const char* n; size_t o; } tab[] = {
-      {"status", L.status}, {"packed", L.packed}, {"packed_bf", L.packed_bf}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
+      {"status", L.status}, {"packed", L.packed}, {"packed_bf", L.packed_bf}, {"bsave", L.bsave}, {"bmask", L.bmask}, {"bG", L.bG}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
       {"rgb_c", L.rgb_c}, {"w_c", L.w_c}, {"t_f", L.t_f}, {"sig_f", L.sig_f}, {"rgb_f", L.rgb_f}, {"perm", L.perm},
       {"w_m", L.w_m}, {"bundle", L.bundle}, {"save", L.save}, {"masks", L.masks}, {"spre", L.spre}, {"G", L.G}, {"dz", L.dz},
       {"dspre", L.dspre}, {"drgb_c", L.drgb_c}, {"dsig_c", L.dsig_c}, {"drgb_f", L.drgb_f}, {"dsig_f", L.dsig_f},

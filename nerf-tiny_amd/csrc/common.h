@@ -62,6 +62,7 @@ struct Grads24 { float* p[24]; };
 struct WsLayout {
   size_t status, packed, packed_bf, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
   // training-only
+  size_t packed_bf_bwd, bsave, bmask, bG, bslabs;  // bf16-MLP training (fragment layout, bf16_common.h)
   size_t perm, w_m, bundle, save, masks, spre, G, dz, dspre, drgb_c, dsig_c, drgb_f, dsig_f, dt_f, slabs, sbuf, gdbuf;
   size_t total;
 };

@@ -16,156 +16,37 @@
 //     (encoding, conversions, heads) runs in the shadow of the other's MFMAs;
 //   * biases are fp32 accumulator start values read from LDS; sigma and colour heads are extra MFMA tiles (row 0 / rows
 //     0..2 of a 32-row tile), 24 MFMAs instead of ~400 VALU instructions.
-#include "bf16_common.h"
-#include "field_common.h"
+#include "bf16_stream.h"
 
 namespace nerf {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BF_NS = 8;        // LDS ring slots
-constexpr int BF_SYNC_POS = 8;  // fragment position inside a chunk at which the next chunk is published
-constexpr int BF_D = 6;         // fragment reads in flight per wave (<= BF_CHUNK - BF_SYNC_POS)
-constexpr int BF_WG = 512;      // 8 waves x 32 samples
-constexpr int BF_LDS_BYTES = BF_BIAS_BYTES + BF_NS * BF_CHUNK * BF_FRAG_BYTES;
-static_assert(BF_D <= BF_CHUNK - BF_SYNC_POS, "a prefetched fragment must not lie in an unpublished chunk");
-
-__device__ __forceinline__ unsigned pack2(float a, float b) {  // two fp32 -> two bf16 (RNE), a in the low half
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ unsigned pack2_relu(float a, float b) {
-  const f32x2 v = {a, b};
-  s16x2 s = __builtin_bit_cast(s16x2, __builtin_convertvector(v, bf16x2));
-  const s16x2 z = {0, 0};
-  s = __builtin_elementwise_max(s, z);  // bf16 as int16: negative values (sign bit) -> 0, positive order preserved
-  return __builtin_bit_cast(unsigned, s);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 63, "vmcnt range");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {  // n is a constant after unrolling
-  switch (n) {
-    case 0: wait_vmcnt<0>(); break;
-    case 2: wait_vmcnt<2>(); break;
-    case 4: wait_vmcnt<4>(); break;
-    case 6: wait_vmcnt<6>(); break;
-    case 8: wait_vmcnt<8>(); break;
-    case 10: wait_vmcnt<10>(); break;
-    case 12: wait_vmcnt<12>(); break;
-    default: wait_vmcnt<0>(); break;
+// ---- store schedule of the training variant (see bf16_stream.h): stores per tile epilogue ------------------------------
+struct FwdTiles { int s0, nft, ks, stores; };
+constexpr FwdTiles kFwdTiles[] = {
+    {BFS_L0, 8, 4, 3},        {BFS_L1, 8, 16, 3},       {BFS_L1 + 128, 8, 16, 3}, {BFS_L1 + 256, 8, 16, 3}, {BFS_L4, 8, 20, 3},
+    {BFS_L5, 8, 16, 3},       {BFS_L5 + 128, 8, 16, 3}, {BFS_L5 + 256, 8, 16, 3}, {BFS_PI, 8, 16, 2},       {BFS_PI + 128, 1, 16, 0},
+    {BFS_DIR, 4, 18, 3},      {BFS_COL, 1, 8, 0}};
+constexpr BfStoreTable<BF_NFRAG> make_fwd_store_table() {
+  BfStoreTable<BF_NFRAG> t{};
+  int ev[BF_NFRAG + 64] = {};
+  for (const FwdTiles& g : kFwdTiles)
+    for (int f = 0; f < g.nft; ++f) ev[g.s0 + (f + 1) * g.ks + BF_EPI_POS] += g.stores;
+  int run = 0;
+  for (int i = 0; i <= BF_NFRAG; ++i) {
+    t.cum[i] = run;  // events strictly before step i
+    run += ev[i];
   }
+  return t;
 }
+constexpr BfStoreTable<BF_NFRAG> kFwdStoreTable = make_fwd_store_table();
 
-struct BfCtx {
-  const unsigned char* wimg;  // global: bias block + fragment stream
-  unsigned char* lds;         // bias block + ring
-  unsigned lds_base;          // the same as an LDS byte address
-  int lane, wv;
+template <bool SAVE>
+struct FwdStream {
+  static constexpr int NFRAG = BF_NFRAG, NCHUNK = BF_NCHUNK, NS = BF_NS, RING_OFF = BF_BIAS_BYTES, D = BF_D;
+  static constexpr bool HAS_BIAS = true;
+  static constexpr int PROLOGUE_STORES = SAVE ? 6 : 0;  // gamma_p (4 pieces) and gamma_d (2)
+  __device__ static constexpr int stores_before(int idx) { return SAVE ? kFwdStoreTable.cum[idx] : 0; }
 };
-
-typedef void __attribute__((address_space(3)))* lptr_t;
-
-// One direct-to-LDS load: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + lane*16 (lds_dst wave-uniform).
-// Inline asm on purpose: hipcc treats a builtin LDS-DMA as a pending write to the whole LDS array and drains the load
-// queue (vmcnt(0)) in front of unrelated ds_reads; hidden from it, the loads are ordered by bf_sync's counted waits alone.
-__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
-// this wave's two 1-KiB pieces of chunk c -> ring slot c % BF_NS
-__device__ __forceinline__ void bf_dma_chunk(const BfCtx& c, int chunk) {
-  const int slot = chunk % BF_NS;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int fr = 2 * c.wv + e;
-    glds16(c.wimg + BF_BIAS_BYTES + ((size_t)chunk * BF_CHUNK + fr) * BF_FRAG_BYTES + c.lane * 16,
-           c.lds_base + BF_BIAS_BYTES + (slot * BF_CHUNK + fr) * BF_FRAG_BYTES);
-  }
-}
-
-// number of this wave's loads that may stay in flight when chunk c + 1 must have landed
-__device__ __forceinline__ constexpr int bf_inflight_after(int c) {
-  const int last = (c + BF_NS - 2 < BF_NCHUNK - 1) ? c + BF_NS - 2 : BF_NCHUNK - 1;  // newest chunk requested so far
-  return (last >= c + 2) ? 2 * (last - (c + 2) + 1) : 0;
-}
-
-// executed by every wave at fragment position BF_SYNC_POS of chunk c
-__device__ __forceinline__ void bf_sync(const BfCtx& c, int chunk) {
-  wait_vmcnt_dyn(bf_inflight_after(chunk));  // my pieces of chunk + 1 are in LDS ...
-  __builtin_amdgcn_s_barrier();              // ... and so are everybody's; everybody is past chunk - 1
-  asm volatile("" ::: "memory");             // no LDS read may be moved above the barrier by the compiler
-  if (chunk + BF_NS - 1 < BF_NCHUNK) bf_dma_chunk(c, chunk + BF_NS - 1);  // into the slot of chunk - 1
-}
-
-__device__ __forceinline__ u32x4 bf_frag(const BfCtx& c, int idx) {
-  const int slot = (idx / BF_CHUNK) % BF_NS;
-  return *reinterpret_cast<const u32x4*>(c.lds + BF_BIAS_BYTES + (slot * BF_CHUNK + idx % BF_CHUNK) * BF_FRAG_BYTES + c.lane * 16);
-}
-
-__device__ __forceinline__ f32x16 bf_bias_tile(const BfCtx& c, int tile) {
-  const int h = c.lane >> 5;
-  f32x16 a;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 q = *reinterpret_cast<const float4*>(c.lds + (tile * 32 + 8 * g + 4 * h) * 4);
-    a[4 * g + 0] = q.x;
-    a[4 * g + 1] = q.y;
-    a[4 * g + 2] = q.z;
-    a[4 * g + 3] = q.w;
-  }
-  return a;
-}
-
-__device__ __forceinline__ f32x16 bf_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// One segment of the stream: NFT output tiles x (KSA + KSB) k-steps starting at fragment S0; inputs inA (k-steps
-// 0..KSA-1) then inB.  fr = ring of BF_D prefetched fragments (fr[idx % BF_D] holds fragment idx on entry to step idx).
-// Two accumulators alternate so that nothing waits for an MFMA result: tile f runs in acc[(P0 + f) & 1]; the finished
-// accumulator of tile f-1 is consumed by epi(f-1, .) BF_EPI_POS k-steps into tile f (the last tile of the previous
-// segment by prev_epi), and right after that it is re-started at the bias of tile f+1 (or of the next segment's tile 0,
-// bias tile NEXT_BT), an LDS read with >= 1 k-steps of MFMAs to land in.
-constexpr int BF_EPI_POS = 2;
-template <int S0, int NFT, int KSA, int KSB, int BT0, int P0, int NEXT_BT, class Epi, class PrevEpi>
-__device__ __forceinline__ void bf_segment(const BfCtx& c, u32x4 (&fr)[BF_D], f32x16 (&acc)[2], const u32x4* inA, const u32x4* inB,
-                                           Epi&& epi, PrevEpi&& prev_epi) {
-  constexpr int KS = KSA + KSB;
-  static_assert(KS > BF_EPI_POS + 1, "segment too short for the deferred epilogue");
-#pragma unroll
-  for (int f = 0; f < NFT; ++f) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int idx = S0 + f * KS + ks;
-      if (idx % BF_CHUNK == BF_SYNC_POS) bf_sync(c, idx / BF_CHUNK);
-      const u32x4 a = fr[idx % BF_D];
-      if (idx + BF_D < BF_NFRAG) fr[idx % BF_D] = bf_frag(c, idx + BF_D);
-      acc[(P0 + f) & 1] = bf_mfma(a, ks < KSA ? inA[ks] : inB[ks - KSA], acc[(P0 + f) & 1]);
-      if (ks == BF_EPI_POS) {
-        if (f == 0)
-          prev_epi(acc[(P0 + 1) & 1]);
-        else
-          epi(f - 1, acc[(P0 + f + 1) & 1]);
-        if (f + 1 < NFT)
-          acc[(P0 + f + 1) & 1] = bf_bias_tile(c, BT0 + f + 1);
-        else if (NEXT_BT >= 0)
-          acc[(P0 + f + 1) & 1] = bf_bias_tile(c, NEXT_BT);
-      }
-    }
-  }
-}
 
 template <bool SAVE>
 __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) {
@@ -191,14 +72,9 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
 #pragma unroll
   for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p[i]), "+v"(dw[i]));  // values are in registers from here on
 
-  // ---- start the weight stream: bias block (as "chunk -1": 2 pieces per wave) and chunks 0 .. BF_NS-2
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int fr = 2 * c.wv + e;
-    glds16(c.wimg + fr * BF_FRAG_BYTES + lane * 16, c.lds_base + fr * BF_FRAG_BYTES);
-  }
-#pragma unroll
-  for (int ch = 0; ch < BF_NS - 1; ++ch) bf_dma_chunk(c, ch);
+  // ---- start the weight stream: bias block and chunks 0 .. BF_NS-2
+  using S = FwdStream<SAVE>;
+  bf_stream_start<S>(c);
 
   // ---- positional encodings straight into B-operand registers (fp32 values as in the fp32 path, rounded to bf16):
   // k-step ks, slot pair (s, s+1): features k = 16ks + 4h + {0,1 | 2,3 | 8,9 | 10,11} = (sin, cos) pairs
@@ -231,23 +107,40 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
       gd[ks][q] = pack2(sv, cv);
     }
 
-  // ---- bias block and chunk 0 have landed (mine), then everybody's
-  wait_vmcnt<2 * (BF_NS - 2)>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  u32x4 fr[BF_D];
+  // ---- training: this wave's block of the fragment-layout save buffers (bf16_common.h); every lane stores, also
+  // lanes beyond the pass (they hold a copy of the last sample): the counted waits rely on the stores being issued
+  const int wb = a.wb0 + blockIdx.x * (BF_WG / 64) + c.wv;
+  unsigned char* const svl = SAVE ? a.bsave + lane * 16 : nullptr;
+  uint16_t* const mkl = SAVE ? a.bmask + lane : nullptr;
+  auto save_piece = [&](int tensor, int ks, const u32x4& v) {
+    *reinterpret_cast<u32x4*>(svl + ((size_t)a.wb_tot * bs_cum(tensor) + (size_t)wb * bs_ks(tensor) + ks) * BF_FRAG_BYTES) = v;
+  };
+  if (SAVE) {
 #pragma unroll
-  for (int i = 0; i < BF_D; ++i) fr[i] = bf_frag(c, i);
+    for (int ks = 0; ks < 4; ++ks) save_piece(BS_GP, ks, gp[ks]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) save_piece(BS_GD, ks, gd[ks]);
+  }
+
+  // ---- bias block and chunk 0 have landed (mine), then everybody's
+  u32x4 fr[S::D];
+  bf_stream_first<S>(c, fr);
 
   u32x4 X[16], Y[16];
   f32x16 acc[2];
   acc[0] = bf_bias_tile(c, BFB_L0);
-  auto relu_to = [&](u32x4* out) {
-    return [out](int f, const f32x16& A) {
+  // epilogue of a ReLU layer: tile f -> packed k-steps 2f, 2f+1 of the next layer's input; training: + save + alive mask
+  auto relu_to = [&](u32x4* out, int tensor = -1, int mlayer = -1) {
+    return [&, out, tensor, mlayer](int f, const f32x16& A) {
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[2 * f + mh][q] = pack2_relu(A[8 * mh + 2 * q], A[8 * mh + 2 * q + 1]);
+      if constexpr (SAVE) {
+        save_piece(tensor, 2 * f, out[2 * f]);
+        save_piece(tensor, 2 * f + 1, out[2 * f + 1]);
+        mkl[(((size_t)mlayer * a.wb_tot + wb) * 8 + f) * 64] = (uint16_t)alive_bits(A);
+      }
     };
   };
   auto last_of = [](auto epi, int f) { return [epi, f](const f32x16& A) { epi(f, A); }; };
@@ -255,14 +148,14 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   auto nothing_f = [](int, const f32x16&) {};
 
   // ---- layers 0..7 (nerf.py:104-112)
-  bf_segment<BFS_L0, 8, 4, 0, BFB_L0, 0, BFB_L0 + 8>(c, fr, acc, gp, nullptr, relu_to(X), nothing);
-  bf_segment<BFS_L1, 8, 16, 0, BFB_L0 + 8, 0, BFB_L0 + 16>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 7));
-  bf_segment<BFS_L1 + 128, 8, 16, 0, BFB_L0 + 16, 0, BFB_L0 + 24>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 7));
-  bf_segment<BFS_L1 + 256, 8, 16, 0, BFB_L0 + 24, 0, BFB_L0 + 32>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 7));
-  bf_segment<BFS_L4, 8, 16, 4, BFB_L0 + 32, 0, BFB_L0 + 40>(c, fr, acc, Y, gp, relu_to(X), last_of(relu_to(Y), 7));
-  bf_segment<BFS_L5, 8, 16, 0, BFB_L0 + 40, 0, BFB_L0 + 48>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 7));
-  bf_segment<BFS_L5 + 128, 8, 16, 0, BFB_L0 + 48, 0, BFB_L0 + 56>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 7));
-  bf_segment<BFS_L5 + 256, 8, 16, 0, BFB_L0 + 56, 0, BFB_PI>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 7));
+  bf_segment<S, BFS_L0, 8, 4, 0, BFB_L0, 0, BFB_L0 + 8>(c, fr, acc, gp, nullptr, relu_to(X, BS_H0 + 0, 0), nothing);
+  bf_segment<S, BFS_L1, 8, 16, 0, BFB_L0 + 8, 0, BFB_L0 + 16>(c, fr, acc, X, nullptr, relu_to(Y, BS_H0 + 1, 1), last_of(relu_to(X, BS_H0 + 0, 0), 7));
+  bf_segment<S, BFS_L1 + 128, 8, 16, 0, BFB_L0 + 16, 0, BFB_L0 + 24>(c, fr, acc, Y, nullptr, relu_to(X, BS_H0 + 2, 2), last_of(relu_to(Y, BS_H0 + 1, 1), 7));
+  bf_segment<S, BFS_L1 + 256, 8, 16, 0, BFB_L0 + 24, 0, BFB_L0 + 32>(c, fr, acc, X, nullptr, relu_to(Y, BS_H0 + 3, 3), last_of(relu_to(X, BS_H0 + 2, 2), 7));
+  bf_segment<S, BFS_L4, 8, 16, 4, BFB_L0 + 32, 0, BFB_L0 + 40>(c, fr, acc, Y, gp, relu_to(X, BS_H0 + 4, 4), last_of(relu_to(Y, BS_H0 + 3, 3), 7));
+  bf_segment<S, BFS_L5, 8, 16, 0, BFB_L0 + 40, 0, BFB_L0 + 48>(c, fr, acc, X, nullptr, relu_to(Y, BS_H0 + 5, 5), last_of(relu_to(X, BS_H0 + 4, 4), 7));
+  bf_segment<S, BFS_L5 + 128, 8, 16, 0, BFB_L0 + 48, 0, BFB_L0 + 56>(c, fr, acc, Y, nullptr, relu_to(X, BS_H0 + 6, 6), last_of(relu_to(Y, BS_H0 + 5, 5), 7));
+  bf_segment<S, BFS_L5 + 256, 8, 16, 0, BFB_L0 + 56, 0, BFB_PI>(c, fr, acc, X, nullptr, relu_to(Y, BS_H0 + 7, 7), last_of(relu_to(X, BS_H0 + 6, 6), 7));
   // ---- point_info (no activation) + sigma head (tile 8, row 0): sigma = |w_sigma . h7 + b|  (nerf.py:94, 113-115)
   float spre = 0.f;
   auto pi_epi = [&](int f, const f32x16& A) {
@@ -271,19 +164,23 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int q = 0; q < 4; ++q) X[2 * f + mh][q] = pack2(A[8 * mh + 2 * q], A[8 * mh + 2 * q + 1]);
+      if constexpr (SAVE) {
+        save_piece(BS_FEAT, 2 * f, X[2 * f]);
+        save_piece(BS_FEAT, 2 * f + 1, X[2 * f + 1]);
+      }
     } else {
       spre = A[0];
     }
   };
-  bf_segment<BFS_PI, 9, 16, 0, BFB_PI, 0, BFB_DIR>(c, fr, acc, Y, nullptr, pi_epi, last_of(relu_to(Y), 7));
+  bf_segment<S, BFS_PI, 9, 16, 0, BFB_PI, 0, BFB_DIR>(c, fr, acc, Y, nullptr, pi_epi, last_of(relu_to(Y, BS_H0 + 7, 7), 7));
   // ---- dir_info on cat(gamma_d, feat), ReLU (nerf.py:117-118); its first tile also retires the sigma tile
-  bf_segment<BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd, X, relu_to(Y), last_of(pi_epi, 8));
+  bf_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd, X, relu_to(Y, BS_C, 8), last_of(pi_epi, 8));
   if (valid && h == 0) {
     a.sigma[m] = fabsf(spre);
     if (SAVE) a.spre[a.row0 + m] = spre;
   }
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
-  bf_segment<BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 3));
+  bf_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y, BS_C, 8), 3));
   if (valid && h == 0) {
     a.rgb[(size_t)m * 3 + 0] = 1.0f / (1.0f + expf(-acc[1][0]));
     a.rgb[(size_t)m * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
@@ -365,11 +262,15 @@ hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st) 
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_bf16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_bf16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES);
+    if (e != hipSuccess) return e;
     attr_done = true;
   }
-  (void)save;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
-  hipLaunchKernelGGL((k_field_fwd_bf16<false>), dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);
+  if (save)
+    hipLaunchKernelGGL((k_field_fwd_bf16<true>), dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);
+  else
+    hipLaunchKernelGGL((k_field_fwd_bf16<false>), dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 

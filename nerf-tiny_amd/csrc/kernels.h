@@ -10,6 +10,9 @@ constexpr int FIELD_LDS_FLOATS = TM * LDA + 4 * TM * 3;
 struct FieldArgs {
   const float4* wp;        // packed weights (PACKED_FWD_F4 float4)
   const unsigned char* wbf;  // bf16 weight stream (bf16_common.h), bf16-MLP variant only
+  unsigned char* bsave;      // bf16 training: saved layer inputs in fragment layout (bf16_common.h)
+  uint16_t* bmask;           // bf16 training: ReLU alive masks
+  int wb0, wb_tot;           // first wave block of this pass, wave blocks of both passes
   Weights24 w;             // raw parameter pointers (biases, sigma / colour heads)
   const float* rayf;       // [B][RAYF]
   const float* dvec;       // [B][128]  b_dir + W_dir[:, :24] * gamma_dir(ray)
@@ -110,6 +113,11 @@ struct FieldBwdArgs {
   float* dz;               // [Mtot][4] colour-head pre-sigmoid gradient
   float* dspre;            // [Mtot]    sigma-head pre-abs gradient
   float* dt;               // [M] fine pass only: in = d loss/d t from the merge, out += direction . d loss/d point
+  // bf16-MLP variant (field_bwd_bf16.hip): transposed stream of this pass, ReLU masks, gradient buffer (fragment layout)
+  const unsigned char* wbf;
+  const uint16_t* bmask;
+  unsigned char* bG;
+  int wb0, wb_tot;
   int row0, tile0, tiles_tot;
   long long Mtot;
   int N, M;
@@ -162,6 +170,11 @@ struct SmallGradArgs {
 
 hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st);
 hipError_t launch_field_bwd_reg(const FieldBwdArgs& a, bool fine, hipStream_t st);
+hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st);
+hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, unsigned char* img, hipStream_t st);
+size_t dw_bf16_slab_floats();
+hipError_t launch_dw_bf16(const unsigned char* G, int g_ks, const unsigned char* X, int x_ks, int wb_tot, float* slabs,
+                          int o_first, int o_count, int nin_real, float* dW, int ldw, int col0, float* db, hipStream_t st);
 hipError_t launch_dw(const DwProblem& p, hipStream_t st);
 size_t dw_slab_floats(int nout, int nin);
 size_t dw_slab_floats_max();

@@ -8,6 +8,7 @@ The reference has no reduced precision, so there is no reference output to be id
       3.8e-3 / 1.1e-2 measured for bf16 weights + activations).
 Tolerances are written next to each assertion.
 """
+import numpy as np
 import pytest
 import torch
 
@@ -70,12 +71,129 @@ def test_forward_bf16(oracle, pkg, dev, name):
     assert not torch.equal(C_c, C_c32)                      # the flag really selects another kernel
 
 
-def test_bf16_training_is_refused(oracle, pkg, dev):
-    g = load_golden("small_16_32")
-    row, col, pb, K, _ = golden_inputs(g)
-    params, _ = _params_dev(oracle, int(g["seed"]), bool(g["sharp"]), dev)
-    m = pkg.NeRFModel(int(g["Nc"]), int(g["Nf"]), row.shape[0]).to(dev)
+# ---------------------------------------------------------------------------------------------------------------
+# training (forward with saving + backward chain + weight-gradient GEMMs, all on bf16 MFMA)
+# ---------------------------------------------------------------------------------------------------------------
+BS_KS = [4] + [16] * 8 + [16, 8, 2]     # bf16_common.h: gamma_p, h0..h7, feat, c, gamma_d
+BG_KS = [16] * 8 + [16, 8, 2]           # dpre0..7, dfeat, dpre_dir, (dz, dspre)
+
+
+def _wave_blocks(B, N):
+    return ((B * N + 255) // 256) * 8
+
+
+def _decode(buf, wb_tot, ks_list, tensor, wb0, nwb):
+    """fragment layout -> [nwb*32 samples, 16*ks features] fp32: piece (wb, ks), lane (j, h), slot s holds feature
+    16ks + 4h + (s&3) + 8(s>>2) of sample wb*32 + j"""
+    ks_t = ks_list[tensor]
+    start = wb_tot * 1024 * sum(ks_list[:tensor])
+    raw = buf[start:start + wb_tot * ks_t * 1024].view(torch.bfloat16).view(wb_tot, ks_t, 2, 32, 8)[wb0:wb0 + nwb].float().cpu()
+    out = torch.zeros(nwb, 32, ks_t * 16)
+    for ks in range(ks_t):
+        for h in range(2):
+            for sl in range(8):
+                out[:, :, 16 * ks + 4 * h + (sl & 3) + 8 * (sl >> 2)] = raw[:, ks, h, :, sl]
+    return out.reshape(nwb * 32, ks_t * 16)
+
+
+def _bf16_model(pkg, params, Nc, Nf, B, dev):
+    m = pkg.NeRFModel(Nc, Nf, B)
     m.load_state_dict(params)
+    m = m.to(dev)
     m.bf16_mlp = True
-    with pytest.raises(RuntimeError, match="BF16_MLP"):
-        m(row.to(dev), col.to(dev), pb.to(dev), K)
+    return m
+
+
+@pytest.mark.parametrize("name", ["small_16_32", "cfg1_lego_crop32"])
+def test_bf16_saved_activations_and_gradients_coarse_only(oracle, pkg, dev, name):
+    """coarse-only loss (d loss / d C_fine = 0: no sort, no resampling in the gradient path -> well conditioned).
+    Saved layer inputs against the emulation; weight gradients against autograd THROUGH the emulation.  The kernels
+    additionally round every gradient that enters an MFMA to bf16 (standard mixed precision): 2^-9 per element and
+    layer, random -> L2-rel <= 3e-2 per tensor (measured: see assertion messages), cosine > 0.999."""
+    from nerf_tiny_amd import _abi
+
+    g = load_golden(name)
+    row, col, pb, K, Ct = golden_inputs(g)
+    Nc, Nf, B = int(g["Nc"]), int(g["Nf"]), row.shape[0]
+    params, _ = _params_dev(oracle, int(g["seed"]), bool(g["sharp"]), dev)
+    m = _bf16_model(pkg, params, Nc, Nf, B, dev)
+    Cc, Cf = m(row.to(dev), col.to(dev), pb.to(dev), K)
+    flags = _abi.SAVE_FOR_BACKWARD | _abi.BF16_MLP
+    ws = next(iter(m._ws.values()))
+    wb_c, wb_tot = _wave_blocks(B, Nc), _wave_blocks(B, Nc) + _wave_blocks(B, Nf)
+    bsave = _abi.ws_view(ws, B, Nc, Nf, flags, "bsave", (wb_tot * sum(BS_KS) * 1024,), torch.uint8)
+
+    # emulation with autograd
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    st = {}
+    Ec, Ef = oracle.render(p, row, col, pb, K, Nc, Nf, stages=st, mlp=oracle.mlp_bf16, check=False)
+    f_p, _ = oracle.frequencies()
+    with torch.no_grad():
+        _, _, hidden, feat, cc = oracle.mlp_bf16(params, oracle.encode(st["pts_c"], f_p), st["gd"][:, None, :].expand(-1, Nc, -1), return_hidden=True)
+    M = B * Nc
+    for tensor, ref in [(1 + l, hidden[l]) for l in (0, 3, 7)] + [(9, feat), (10, cc)]:
+        got = _decode(bsave, wb_tot, BS_KS, tensor, 0, wb_c)[:M]
+        ref = ref.reshape(M, -1)
+        d = (got[:, :ref.shape[1]] - ref).abs()
+        scale = float(ref.abs().max())
+        assert float(d.max()) < 3e-2 * scale, (tensor, float(d.max()), scale)          # a flipped rounding upstream shows here
+        assert float((d > 1e-6 * scale).float().mean()) < 0.05, tensor                 # ... but most entries are identical
+    loss = torch.sum(torch.square(Cc - Ct.to(dev)))
+    loss.backward()
+    eloss = torch.sum(torch.square(Ec - Ct))
+    eloss.backward()
+    assert abs(float(loss) - float(eloss)) < 5e-3 * abs(float(eloss))
+    for (k, pe), pm in zip(p.items(), m.network.parameters()):
+        ge, gm = pe.grad.double().flatten(), pm.grad.double().flatten().cpu()
+        assert torch.isfinite(gm).all(), k
+        rel = float((gm - ge).norm() / ge.norm().clamp_min(1e-30))
+        cos = float(torch.dot(gm, ge) / (gm.norm() * ge.norm()).clamp_min(1e-30))
+        assert rel < 3e-2 and cos > 0.999, (k, rel, cos)
+
+
+@pytest.mark.parametrize("name", ["small_16_32", "cfg1_lego_crop32"])
+def test_bf16_full_loss_gradients(oracle, pkg, dev, name):
+    """whole train step with both colours in the loss.  The full gradient is ill-conditioned already in fp32
+    (tests/test_gpu_backward.py: per-channel sort ties, ReLU kinks on the t_fine path); here it must be finite, give the
+    emulation's loss and stay inside the same band against autograd through the emulation."""
+    g = load_golden(name)
+    row, col, pb, K, Ct = golden_inputs(g)
+    Nc, Nf, B = int(g["Nc"]), int(g["Nf"]), row.shape[0]
+    params, _ = _params_dev(oracle, int(g["seed"]), bool(g["sharp"]), dev)
+    m = _bf16_model(pkg, params, Nc, Nf, B, dev)
+    Cc, Cf = m(row.to(dev), col.to(dev), pb.to(dev), K)
+    loss = m.ray_loss(Cc, Cf, Ct.to(dev))
+    loss.backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Ec, Ef = oracle.render(p, row, col, pb, K, Nc, Nf, mlp=oracle.mlp_bf16, check=False)
+    eloss = oracle.ray_loss(Ec, Ef, Ct)
+    eloss.backward()
+    assert abs(float(loss) - float(eloss)) < 2e-2 * abs(float(eloss))
+    worst = 0.0
+    for (k, pe), pm in zip(p.items(), m.network.parameters()):
+        ge, gm = pe.grad.double().flatten(), pm.grad.double().flatten().cpu()
+        assert torch.isfinite(gm).all(), k
+        worst = max(worst, float((gm - ge).norm() / ge.norm().clamp_min(1e-30)))
+    assert worst < 0.5, worst
+
+
+def test_bf16_training_learns(pkg, dev):
+    """a few fused-Adam steps in bf16 mode on a synthetic scene reduce the loss"""
+    ds = pkg.data.synthetic_scene(n_pic=4, H=32, W=32, seed=3)
+    rays = pkg.data.DeviceRays(ds, dev, seed=1)
+    m = pkg.NeRFModel(32, 64, 1024).to(dev)
+    m.bf16_mlp = True
+    opt = pkg.train.FusedAdam(list(m.network.parameters()), lr=5e-4)
+    K = torch.tensor([[1.0, 0.0, -16.0], [0.0, -1.0, 16.0], [0.0, 0.0, -float(ds.focal)]]).t()
+    losses = []
+    idx = torch.randperm(rays.num_pix, device=dev, generator=rays.gen)[:1024]
+    row, col, pix, pb, _ = rays.gather(idx)
+    for _ in range(30):
+        opt.zero_grad()
+        Cc, Cf = m(row, col, pb, K)
+        loss = m.ray_loss(Cc, Cf, pix)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
