@@ -136,21 +136,40 @@ struct DwBfReduceArgs {
   float* db;                    // or null
 };
 
+// 64 output elements per block; the slabs are split over 4 thread groups whose partial sums are added in a fixed order
 __global__ __launch_bounds__(256) void k_dw_bf16_reduce(const DwBfReduceArgs a) {
+  __shared__ float part[4][64];
   const int ld = a.ni + 1;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.o_count * ld) return;
-  const int o = idx / ld, i = idx - o * ld;
-  if (i < a.ni && i >= a.nin_real) return;
-  if (i == a.ni && a.db == nullptr) return;
-  const float* p = a.slabs + (size_t)(a.o_first + o) * ld + i;
-  const size_t stride = (size_t)a.rows * ld;
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  const bool in_range = idx < a.o_count * ld;
+  const int o = in_range ? idx / ld : 0, i = in_range ? idx - o * ld : 0;
+  const bool wanted = in_range && ((i < a.ni && i < a.nin_real) || (i == a.ni && a.db != nullptr));
   float s = 0.f;
-  for (int k = 0; k < a.nslab; ++k) s += p[(size_t)k * stride];
-  if (i == a.ni)
-    a.db[o] = s;
-  else
-    a.dW[(size_t)o * a.ldw + a.col0 + i] = s;
+  if (wanted) {
+    const float* p = a.slabs + (size_t)(a.o_first + o) * ld + i;
+    const size_t stride = (size_t)a.rows * ld;
+    const int per = (a.nslab + 3) / 4, k0 = grp * per, k1 = min(a.nslab, k0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      s0 += p[(size_t)k * stride];
+      s1 += p[(size_t)(k + 1) * stride];
+      s2 += p[(size_t)(k + 2) * stride];
+      s3 += p[(size_t)(k + 3) * stride];
+    }
+    for (; k < k1; ++k) s0 += p[(size_t)k * stride];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && wanted) {
+    const float t = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    if (i == a.ni)
+      a.db[o] = t;
+    else
+      a.dW[(size_t)o * a.ldw + a.col0 + i] = t;
+  }
 }
 
 size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * 256 * 257; }
@@ -183,7 +202,7 @@ hipError_t launch_dw_bf16(const unsigned char* G, int g_ks, const unsigned char*
   r.slabs = slabs; r.nslab = wgs; r.rows = a.o_tiles * 32; r.ni = x_ks * 16;
   r.o_first = o_first; r.o_count = o_count; r.nin_real = nin_real; r.dW = dW; r.ldw = ldw; r.col0 = col0; r.db = db;
   const int n = o_count * (r.ni + 1);
-  hipLaunchKernelGGL(k_dw_bf16_reduce, dim3((n + 255) / 256), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(k_dw_bf16_reduce, dim3((n + 63) / 64), dim3(256), 0, st, r);
   return hipGetLastError();
 }
 
