@@ -22,6 +22,7 @@ if __name__ == "__main__":
     ap.add_argument("--conf-dir", type=str, default=os.path.join(HERE, "conf"))
     ap.add_argument("--synthetic", action="store_true", help="procedural scene instead of IMG_DIR")
     ap.add_argument("--total-iter", type=int, default=None)
+    ap.add_argument("--bf16-mlp", action="store_true", help="run the MLP on bf16 MFMA (cfg3; also ini key BF16_MLP = True)")
     args = ap.parse_args()
     conf = ConfigParser()
     conf.read(os.path.join(args.conf_dir, args.conf + ".ini"))
@@ -34,6 +35,7 @@ if __name__ == "__main__":
     if args.synthetic:
         scene = P.data.synthetic_scene(n_pic=8, H=64, W=64)
         kw["datasets"] = {"train": scene, "val": scene, "test": scene}
+    kw["bf16_mlp"] = args.bf16_mlp or ast.literal_eval(c("BF16_MLP", "False"))
     run = P.NeRFRunner(**kw)
     run.trainer("train")
     run.display()

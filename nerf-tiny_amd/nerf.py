@@ -76,7 +76,7 @@ class _RenderFn(torch.autograd.Function):
         B = row.shape[0]
         Nc, Nf = model.num_coarse, model.num_fine
         flags = ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
-                 | (_abi.BF16_MLP if model.bf16_mlp else 0))
+                 | (_abi.BF16_MLP if getattr(model, "bf16_mlp", False) else 0))
         ws = model._workspace(B, flags)
         dev = row.device
         C_c = torch.empty(B, 3, dtype=torch.float32, device=dev)
