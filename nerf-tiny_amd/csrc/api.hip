@@ -374,21 +374,31 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     float* slabs = at<float>(ws, L.bslabs);
     auto X = [&](int t) { return bs + (size_t)wb_tot * bs_cum(t) * BF_FRAG_BYTES; };
     auto Gt = [&](int t) { return bg + (size_t)wb_tot * bg_cum(t) * BF_FRAG_BYTES; };
+    int ns = 0;
     // layer 0: X = gamma_p
-    HIP_TRY(launch_dw_bf16(Gt(BG_L0), 16, X(BS_GP), 4, wb_tot, slabs, 0, 256, POINT_DIM, dw[0], POINT_DIM, 0, dw[1], st));
-    for (int l = 1; l <= 7; ++l)
-      HIP_TRY(launch_dw_bf16(Gt(BG_L0 + l), 16, X(BS_H0 + l - 1), 16, wb_tot, slabs, 0, 256, WIDTH, dw[2 * l],
-                             (l == 4) ? WIDTH + POINT_DIM : WIDTH, 0, dw[2 * l + 1], st));
-    // layer 4, skip columns
-    HIP_TRY(launch_dw_bf16(Gt(BG_L0 + 4), 16, X(BS_GP), 4, wb_tot, slabs, 0, 256, POINT_DIM, dw[8], WIDTH + POINT_DIM, WIDTH, nullptr, st));
-    // point_info; sigma head = row 3 of the dz/dspre tile against the same h7
-    HIP_TRY(launch_dw_bf16(Gt(BG_PI), 16, X(BS_H0 + 7), 16, wb_tot, slabs, 0, 256, WIDTH, dw[W_PI], WIDTH, 0, dw[B_PI], st));
-    HIP_TRY(launch_dw_bf16(Gt(BG_Z), 2, X(BS_H0 + 7), 16, wb_tot, slabs, 3, 1, WIDTH, dw[W_SIGMA], WIDTH, 0, dw[B_SIGMA], st));
-    // dir_info: feature columns, then direction columns
-    HIP_TRY(launch_dw_bf16(Gt(BG_D), 8, X(BS_FEAT), 16, wb_tot, slabs, 0, HALF, WIDTH, dw[W_DIR], WIDTH + DIR_DIM, DIR_DIM, dw[B_DIR], st));
-    HIP_TRY(launch_dw_bf16(Gt(BG_D), 8, X(BS_GD), 2, wb_tot, slabs, 0, HALF, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, nullptr, st));
-    // colour head = rows 0..2 of the dz/dspre tile against c
-    HIP_TRY(launch_dw_bf16(Gt(BG_Z), 2, X(BS_C), 8, wb_tot, slabs, 0, 3, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR], st));
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1], st));
+    for (int l = 1; l <= 7; ++l) {
+      if (l == 4) {  // one pass over dpre4 for both column groups of the [256][316] matrix: X = [h3 | gamma_p]
+        HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
+        HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9], st));
+      } else {
+        HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + l), 16, X(BS_H0 + l - 1), 16, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
+        HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 256, 0, 256, 0, WIDTH, dw[2 * l], WIDTH, 0, dw[2 * l + 1], st));
+      }
+    }
+    // point_info, and in the same pass over h7 the sigma head: row 3 of h7^T (dz, dspre)
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_PI), 16, X(BS_H0 + 7), 16, nullptr, 0, Gt(BG_Z), wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 288, 256, 0, 256, 0, WIDTH, dw[W_PI], WIDTH, 0, dw[B_PI], st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 288, 256, 256 + 3, 1, 0, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr, st));
+    // dir_info: X = [gamma_d | feat] (24 of the first 32 columns are real)
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_D), 8, X(BS_GD), 2, X(BS_FEAT), 16, nullptr, wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 128, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR], st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 128, 288, 0, HALF, 32, WIDTH, dw[W_DIR], WIDTH + DIR_DIM, DIR_DIM, nullptr, st));
+    // colour head = rows 0..2 of the (dz, dspre) tile against c; row 3 of its column sums = the sigma bias gradient
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR], st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA], st));
   } else {
     ProfScope ps(NERF_HIP_K_BWD_DW, st);
     DwProblem p;

@@ -22,17 +22,17 @@ namespace nerf {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef s16x4 __attribute__((address_space(3)))* lds_s16x4_p;
 
-constexpr int DWB_NSLOT = 4;
-constexpr int DWB_SLOT_BYTES = 32 * 1024;  // G (<= 16 KiB) + X (<= 16 KiB) of one wave block
-constexpr int DWB_LDS_BYTES = DWB_NSLOT * DWB_SLOT_BYTES;
 constexpr int DWB_WGS = 256;
 
 struct DwBfArgs {
-  const unsigned char* G;  // start of the gradient tensor (fragment layout), g_ks pieces per wave block
-  const unsigned char* X;  // start of the input tensor, x_ks = 2 * NIT pieces per wave block
-  int g_ks, o_tiles;       // o_tiles = output row tiles (waves w >= o_tiles only help loading)
+  const unsigned char* G;   // start of the gradient tensor (fragment layout), g_ks pieces per wave block
+  const unsigned char* X1;  // input tensor(s): the i index runs over X1's x1_ks pieces, then X2's (2 * NIT - x1_ks)
+  const unsigned char* X2;
+  const unsigned char* Z;   // HAS_Z: a second, 2-piece gradient tensor whose product with X is formed as well (X^T Z)
+  int g_ks, o_tiles;        // o_tiles = output row tiles (waves w >= o_tiles only help loading)
+  int x1_ks;
   int wb_tot;
-  float* slabs;            // [gridDim.x][o_tiles*32][NIT*32 + 1]  (last column: sum of G over the samples)
+  float* slabs;             // [gridDim.x][o_tiles*32 (+32 with Z)][NIT*32 + 1]  (last column: sum of G over the samples)
 };
 
 // LDS unit (16 bytes) of (piece ks, half h, sample s) inside a tensor block: the sample index is XOR-swizzled
@@ -53,54 +53,76 @@ __device__ __forceinline__ u32x4 dwb_operand(const unsigned char* blk, int t, in
   return r;
 }
 
-template <int NIT>
+template <int NIT, bool HAS_Z>
+struct DwbGeom {
+  static constexpr int XKS = 2 * NIT;
+  static constexpr int PIECES = 16 + XKS + (HAS_Z ? 2 : 0);   // slot layout: G at piece 0, X at 16, Z at 16 + XKS
+  static constexpr int SLOT_BYTES = PIECES * BF_FRAG_BYTES;
+  static constexpr int NSLOT = 4;
+  static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;
+  static constexpr int NPW = (PIECES + 7) / 8;                // loads per wave and block
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int NIT, bool HAS_Z>
 __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int XKS = 2 * NIT;
+  using Geo = DwbGeom<NIT, HAS_Z>;
+  constexpr int XKS = Geo::XKS, NSLOT = Geo::NSLOT, NPW = Geo::NPW;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
   const int per = (a.wb_tot + gridDim.x - 1) / gridDim.x;
   const int b_lo = blockIdx.x * per, b_hi = min(a.wb_tot, b_lo + per);
   const int nb = b_hi - b_lo;
-  const int gks = a.g_ks, total = gks + XKS;
-  const bool worker = wv < a.o_tiles;
+  const int gks = a.g_ks, x1 = a.x1_ks, total = gks + XKS + (HAS_Z ? 2 : 0);
+  const bool worker = wv < a.o_tiles, zworker = HAS_Z && wv < NIT;
 
-  f32x16 acc[NIT], accb;
+  f32x16 acc[NIT], accb, accz;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NIT; ++i) acc[i] = zero;
   accb = zero;
+  accz = zero;
   const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};  // bf16 1.0 pairs
 
   // pieces of a block are dealt round-robin to the waves; every wave issues the same NUMBER of loads per block (the
-  // counted wait needs that): a wave whose turn falls beyond the last piece loads the last piece again
-  constexpr int NPW = 4;  // ceil((16 + 16) / 8); also used for smaller tensors (duplicates are harmless)
-  // swizzled source lane: LDS lane L of a piece holds sample (L & 31) ^ swz of half L >> 5
+  // counted wait needs that): a wave whose turn falls beyond the last piece loads the last piece again.
+  // Swizzle on the source side: LDS lane L of a piece holds sample (L & 31) ^ swz of half L >> 5.
   auto dma_block = [&](int b, int slot) {
     const int wb = b_lo + (b < nb ? b : nb - 1);
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
       int pc = wv + 8 * k;
       pc = pc < total ? pc : total - 1;
-      const bool is_g = pc < gks;
-      const int ks = is_g ? pc : pc - gks;
+      const unsigned char* src;
+      int ks, dst;
+      if (pc < gks) {
+        ks = pc; dst = ks;
+        src = a.G + ((size_t)wb * gks + ks) * BF_FRAG_BYTES;
+      } else if (pc < gks + XKS) {
+        const int x = pc - gks;
+        ks = x; dst = 16 + x;  // parity of the slot piece = parity of x (x1_ks is even)
+        src = x < x1 ? a.X1 + ((size_t)wb * x1 + x) * BF_FRAG_BYTES : a.X2 + ((size_t)wb * (XKS - x1) + (x - x1)) * BF_FRAG_BYTES;
+      } else {
+        ks = pc - gks - XKS; dst = 16 + XKS + ks;
+        src = a.Z + ((size_t)wb * 2 + ks) * BF_FRAG_BYTES;
+      }
       const int h = lane >> 5, s = (lane & 31) ^ (4 * (2 * (ks & 1) + h));
-      const unsigned char* src = is_g ? a.G + ((size_t)wb * gks + ks) * BF_FRAG_BYTES : a.X + ((size_t)wb * XKS + ks) * BF_FRAG_BYTES;
-      glds16(src + (h * 32 + s) * 16, lds_base + slot * DWB_SLOT_BYTES + (is_g ? ks : 16 + ks) * BF_FRAG_BYTES);
+      glds16(src + (h * 32 + s) * 16, lds_base + slot * Geo::SLOT_BYTES + dst * BF_FRAG_BYTES);
     }
   };
   if (nb > 0) {
 #pragma unroll
-    for (int b = 0; b < DWB_NSLOT - 1; ++b) dma_block(b, b);
+    for (int b = 0; b < NSLOT - 1; ++b) dma_block(b, b);
     for (int b = 0; b < nb; ++b) {
-      wait_vmcnt<(DWB_NSLOT - 2) * NPW>();  // my pieces of block b are in LDS ...
-      __builtin_amdgcn_s_barrier();         // ... and everybody's; everybody is done with block b - 1
+      wait_vmcnt<(NSLOT - 2) * NPW>();  // my pieces of block b are in LDS ...
+      __builtin_amdgcn_s_barrier();     // ... and everybody's; everybody is done with block b - 1
       asm volatile("" ::: "memory");
-      dma_block(b + DWB_NSLOT - 1, (b + DWB_NSLOT - 1) % DWB_NSLOT);  // into the slot of block b - 1
+      dma_block(b + NSLOT - 1, (b + NSLOT - 1) % NSLOT);  // into the slot of block b - 1
+      const unsigned char* gb = lds + (b % NSLOT) * Geo::SLOT_BYTES;
+      const unsigned char* xb = gb + 16 * BF_FRAG_BYTES;
       if (worker) {
-        const unsigned char* gb = lds + (b % DWB_NSLOT) * DWB_SLOT_BYTES;
-        const unsigned char* xb = gb + 16 * BF_FRAG_BYTES;
 #pragma unroll
         for (int kstep = 0; kstep < 2; ++kstep) {
           const u32x4 A = dwb_operand(gb, wv, kstep, lane);
@@ -109,14 +131,20 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
           accb = bf_mfma(A, ones, accb);
         }
       }
+      if (zworker) {  // rows = this wave's X tile, columns = Z features: (X^T Z) tile
+        const unsigned char* zb = xb + XKS * BF_FRAG_BYTES;
+#pragma unroll
+        for (int kstep = 0; kstep < 2; ++kstep) accz = bf_mfma(dwb_operand(xb, wv, kstep, lane), dwb_operand(zb, 0, kstep, lane), accz);
+      }
     }
     wait_vmcnt<0>();  // nothing may still be writing this workgroup's LDS when it ends
   }
+  // accumulator layout: lane l holds column l & 31 and rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+  const int NI = NIT * 32, ld = NI + 1;
+  const int rows = a.o_tiles * 32 + (HAS_Z ? 32 : 0);
+  float* slab = a.slabs + (size_t)blockIdx.x * rows * ld;
+  const int n = lane & 31, hh = lane >> 5;
   if (worker) {
-    // accumulator layout: lane l holds column i = l & 31 and rows o = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
-    const int NI = NIT * 32, ld = NI + 1;
-    float* slab = a.slabs + (size_t)blockIdx.x * (a.o_tiles * 32) * ld;
-    const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -125,13 +153,20 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
       if (n == 0) slab[(size_t)o * ld + NI] = accb[r];
     }
   }
+  if (zworker) {  // slab row o_tiles*32 + z, column i
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      slab[(size_t)(a.o_tiles * 32 + n) * ld + i] = accz[r];
+    }
+  }
 }
 
-// dW[o_first + o][col0 + i] = sum over slabs, i < nin_real; db[o] likewise from the last slab column
+// dW[o][col0 + i - i_first] = sum over slabs of row o_first + o, column i; db[o] likewise from the last slab column
 struct DwBfReduceArgs {
   const float* slabs;
   int nslab, rows, ni;          // slab = [rows][ni + 1]
-  int o_first, o_count, nin_real;
+  int o_first, o_count, i_first, i_count;   // slab columns [i_first, i_first + i_count) -> dW columns col0 ..
   float* dW; int ldw, col0;
   float* db;                    // or null
 };
@@ -144,7 +179,7 @@ __global__ __launch_bounds__(256) void k_dw_bf16_reduce(const DwBfReduceArgs a) 
   const int idx = blockIdx.x * 64 + e;
   const bool in_range = idx < a.o_count * ld;
   const int o = in_range ? idx / ld : 0, i = in_range ? idx - o * ld : 0;
-  const bool wanted = in_range && ((i < a.ni && i < a.nin_real) || (i == a.ni && a.db != nullptr));
+  const bool wanted = in_range && ((i < a.ni && i >= a.i_first && i < a.i_first + a.i_count && a.dW != nullptr) || (i == a.ni && a.db != nullptr));
   float s = 0.f;
   if (wanted) {
     const float* p = a.slabs + (size_t)(a.o_first + o) * ld + i;
@@ -168,40 +203,52 @@ __global__ __launch_bounds__(256) void k_dw_bf16_reduce(const DwBfReduceArgs a) 
     if (i == a.ni)
       a.db[o] = t;
     else
-      a.dW[(size_t)o * a.ldw + a.col0 + i] = t;
+      a.dW[(size_t)o * a.ldw + a.col0 + (i - a.i_first)] = t;
   }
 }
 
-size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * 256 * 257; }
+size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * (256 + 32) * (320 + 1); }
 
-// One weight-gradient GEMM.  G: g_ks pieces per wave block (o_tiles = ceil(g_ks / 2) row tiles), X: x_ks in {16, 8, 4, 2}.
-hipError_t launch_dw_bf16(const unsigned char* G, int g_ks, const unsigned char* X, int x_ks, int wb_tot, float* slabs,
-                          int o_first, int o_count, int nin_real, float* dW, int ldw, int col0, float* db, hipStream_t st) {
+template <int NIT, bool HAS_Z>
+static hipError_t dwb_launch(const DwBfArgs& a, int wgs, hipStream_t st) {
   static bool attr_done = false;
+  using Geo = DwbGeom<NIT, HAS_Z>;
   if (!attr_done) {
-    hipError_t e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw_bf16<8>), hipFuncAttributeMaxDynamicSharedMemorySize, DWB_LDS_BYTES)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw_bf16<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DWB_LDS_BYTES)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw_bf16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DWB_LDS_BYTES)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw_bf16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, DWB_LDS_BYTES)) != hipSuccess) return e;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw_bf16<NIT, HAS_Z>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES);
+    if (e != hipSuccess) return e;
     attr_done = true;
   }
+  hipLaunchKernelGGL((k_dw_bf16<NIT, HAS_Z>), dim3(wgs), dim3(BF_WG), Geo::LDS_BYTES, st, a);
+  return hipGetLastError();
+}
+
+// One pass over the samples: slabs <- G^T [X1 | X2]  (+ [X1 | X2]^T Z in 32 extra slab rows).  x1_ks + x2_ks in {2,4,8,16,18,20}.
+hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned char* X1, int x1_ks, const unsigned char* X2, int x2_ks,
+                               const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st) {
   DwBfArgs a;
-  a.G = G; a.X = X; a.g_ks = g_ks; a.o_tiles = (g_ks + 1) / 2; a.wb_tot = wb_tot; a.slabs = slabs;
+  a.G = G; a.X1 = X1; a.X2 = X2 ? X2 : X1; a.Z = Z; a.g_ks = g_ks; a.o_tiles = (g_ks + 1) / 2; a.x1_ks = x1_ks; a.wb_tot = wb_tot; a.slabs = slabs;
   const int wgs = wb_tot < DWB_WGS ? wb_tot : DWB_WGS;
-  switch (x_ks) {
-    case 16: hipLaunchKernelGGL((k_dw_bf16<8>), dim3(wgs), dim3(BF_WG), DWB_LDS_BYTES, st, a); break;
-    case 8: hipLaunchKernelGGL((k_dw_bf16<4>), dim3(wgs), dim3(BF_WG), DWB_LDS_BYTES, st, a); break;
-    case 4: hipLaunchKernelGGL((k_dw_bf16<2>), dim3(wgs), dim3(BF_WG), DWB_LDS_BYTES, st, a); break;
-    case 2: hipLaunchKernelGGL((k_dw_bf16<1>), dim3(wgs), dim3(BF_WG), DWB_LDS_BYTES, st, a); break;
+  *nslab = wgs;
+  const int xks = x1_ks + x2_ks;
+  if (Z) return xks == 16 ? dwb_launch<8, true>(a, wgs, st) : hipErrorInvalidValue;
+  switch (xks) {
+    case 20: return dwb_launch<10, false>(a, wgs, st);
+    case 18: return dwb_launch<9, false>(a, wgs, st);
+    case 16: return dwb_launch<8, false>(a, wgs, st);
+    case 8: return dwb_launch<4, false>(a, wgs, st);
+    case 4: return dwb_launch<2, false>(a, wgs, st);
+    case 2: return dwb_launch<1, false>(a, wgs, st);
     default: return hipErrorInvalidValue;
   }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+}
+
+// slab rows [o_first, o_first + o_count), columns [i_first, i_first + i_count) -> dW[o][col0 + i]; last slab column -> db
+hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count,
+                                 float* dW, int ldw, int col0, float* db, hipStream_t st) {
   DwBfReduceArgs r;
-  r.slabs = slabs; r.nslab = wgs; r.rows = a.o_tiles * 32; r.ni = x_ks * 16;
-  r.o_first = o_first; r.o_count = o_count; r.nin_real = nin_real; r.dW = dW; r.ldw = ldw; r.col0 = col0; r.db = db;
-  const int n = o_count * (r.ni + 1);
+  r.slabs = slabs; r.nslab = nslab; r.rows = rows; r.ni = ni;
+  r.o_first = o_first; r.o_count = o_count; r.i_first = i_first; r.i_count = i_count; r.dW = dW; r.ldw = ldw; r.col0 = col0; r.db = db;
+  const int n = o_count * (ni + 1);
   hipLaunchKernelGGL(k_dw_bf16_reduce, dim3((n + 63) / 64), dim3(256), 0, st, r);
   return hipGetLastError();
 }
