@@ -22,7 +22,7 @@ for k, cs in acc.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]:
         d["mfma_busy_over_sq_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CYCLES"]
     key = k
-    if "k_field_fwd" in k:  # the dominant kernel of bench.py, whichever instantiation ran
+    if "k_field_fwd" in k and "bf16" not in k:  # the dominant kernel of bench.py, whichever fp32 instantiation ran
         key = "k_field_fwd"
     out[key] = d
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
@@ -31,5 +31,5 @@ json.dump(out, open(p, "w"), indent=1, sort_keys=True)
 if mode == "forward":
     json.dump(out, open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(out):
-    if "field" in k or "k_dw" == k:
+    if "field" in k or k.startswith("k_dw"):
         print(k, json.dumps(out[k], sort_keys=True))
