@@ -5,7 +5,6 @@
 
 #include <stdarg.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <math.h>
 #include <string.h>
 
@@ -56,7 +55,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
   L.status = take(256);
-  L.packed = take((size_t)PACKED_ALL_F4 * 16 + PACKED_HEAD_BYTES);
+  L.packed = take((size_t)PACKED_ALL_F4 * 16);
   if (flags & NERF_HIP_BF16_MLP) L.packed_bf = take(BF_IMAGE_BYTES);
   L.rayf = take(b * RAYF * 4);
   L.dvec = take(b * HALF * 4);
@@ -191,7 +190,6 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     ProfScope ps(NERF_HIP_K_PACK, st);
     if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
     else HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
-    if (!bf16 && !save) HIP_TRY(launch_pack_head_block(w, at<float4>(ws, L.packed), st));
   }
 
   RaysArgs ra;
@@ -232,13 +230,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     }
   }
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  static const bool use_ring = [] { const char* e = getenv("NERF_HIP_FWD_KERNEL"); return !(e && strcmp(e, "reg") == 0); }();
-  auto field = [&](const FieldArgs& f) {
-    if (bf16) return launch_field_fwd_bf16(f, save, st);
-    if (tile_kernel) return launch_field_fwd(f, save, st);
-    if (!save && use_ring) return launch_field_fwd_ring(f, st);  // inference: weights shared through an LDS ring
-    return launch_field_fwd_reg(f, save, st);
-  };
+  auto field = [&](const FieldArgs& f) { return bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
   { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(field(fa)); }
 
   CoarseArgs ca;

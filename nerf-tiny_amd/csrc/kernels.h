@@ -84,9 +84,6 @@ hipError_t launch_pack_weights(const Weights24& w, float4* out, int nseg, hipStr
 hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st);
-hipError_t launch_field_fwd_ring(const FieldArgs& a, hipStream_t st);
-hipError_t launch_pack_head_block(const Weights24& w, float4* packed, hipStream_t st);
-constexpr int PACKED_HEAD_BYTES = 16384;  // head block behind the packed segments (field_fwd_ring.hip)
 hipError_t launch_pack_weights_bf16(const Weights24& w, unsigned char* img, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
 hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st);
