@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 1
+#define NERF_HIP_ABI_VERSION 2 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16 */
 
 enum {
   NERF_HIP_OK = 0,

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_HIP_LIB", os.path.join(_HERE, "libnerf_hip.so"))  # override: diagnostic builds only
 
-NERF_HIP_ABI_VERSION = 1
+NERF_HIP_ABI_VERSION = 2
 SAVE_FOR_BACKWARD = 1 << 0
 FORCE_TILE_KERNEL = 1 << 1
 BF16_MLP = 1 << 2
