@@ -138,6 +138,10 @@ def main():
     ap.add_argument("--mlp", choices=["f32", "bf16"], default="f32",
                     help="f32 = the headline metric (reference precision); bf16 = BASELINE.json cfg3 'bf16 MLP / fp32 composite' "
                          "(NOT the headline: reduced precision, reported as its own metric)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): every rank renders its own 4096-ray batches; strong: ONE 4096-ray "
+                         "batch is split into contiguous slices of 4096/N rays (SURVEY.md 8d cfg3), with the global ray 0's (near, far) "
+                         "handed to every rank (quirk Q6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -165,10 +169,24 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")  # only the single-rank rehearsal comes without a launcher's environment
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    row, col, pb, K, C_true = synth_inputs(seed=1000 + rank)
+    strong = args.scaling == "strong"
+    row, col, pb, K, C_true = synth_inputs(seed=1000 + (0 if strong else rank))
     model = synth_weights(seed=0).to(dev)
+    b_local = B
+    if strong:
+        if B % world:
+            raise SystemExit(f"--scaling strong needs {B} % N == 0")
+        b_local = B // world
+        sl = slice(rank * b_local, (rank + 1) * b_local)
+        ray0 = (float(pb[0, 15]), float(pb[0, 16]))  # the GLOBAL ray 0's spacing goes to every shard (nerf.py:233)
+        row, col, pb, C_true = row[sl], col[sl], pb[sl], C_true[sl]
+        model.batch_ray = b_local
+        model.ray0_near_far = ray0
     bf16 = args.mlp == "bf16"
     model.bf16_mlp = bf16
     row, col, pb, C_true = row.to(dev), col.to(dev), pb.float().to(dev), C_true.to(dev)
@@ -211,14 +229,14 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        rays = B * world * args.steps
+        rays = (B if strong else B * world) * args.steps
         value = rays / elapsed
         # dominant kernel: k_field_fwd, launched twice per step (coarse pass B*Nc samples, fine pass B*Nf samples);
         # "launch" = the average launch, so that rocprofv3's per-kernel average is directly comparable.
         ms_sum = prof.get("field_fwd_coarse", (0.0, 0))[0] + prof.get("field_fwd_fine", (0.0, 0))[0]
         n_launch = prof.get("field_fwd_coarse", (0.0, 0))[1] + prof.get("field_fwd_fine", (0.0, 0))[1]
         avg_ms = ms_sum / max(n_launch, 1)
-        flop_launch = FLOP_PER_SAMPLE * B * (NC + NF) // 2
+        flop_launch = FLOP_PER_SAMPLE * b_local * (NC + NF) // 2
         achieved = flop_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         flop_ray = FLOP_PER_RAY_TRAIN if train else FLOP_PER_RAY_FWD
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
@@ -226,12 +244,12 @@ def main():
             "metric": "rays/sec (64 coarse + 128 fine samples), lego 400x400" + (" [train step: fwd+loss+bwd]" if train else "")
                       + (" [cfg3: bf16 MLP / fp32 composite]" if bf16 else ""),
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": ("cfg3: lego-like 400x400 view, 4096-ray batches, 64 coarse + 128 fine samples, bf16 MLP (fp32 accumulate) / fp32 "
                                     "everything else, " if bf16 else
                                     "cfg2: lego-like 400x400 view, 4096-ray batches, 64 coarse + 128 fine samples, fp32, ")
-                                   + "random-init 8x256 NeRF MLP (593,924 params)", "rays_per_step_per_gpu": B,
+                                   + "random-init 8x256 NeRF MLP (593,924 params)", "rays_per_step_per_gpu": b_local,
                        "mode": args.mode, "parallelism": f"ray-batch x{world} (independent batches, no collective)" if not train else
                        f"ray-batch DP x{world} (one flat SUM all-reduce of 593,924 fp32 gradients per step)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -239,7 +257,7 @@ def main():
                          "kernel": ("k_field_fwd_bf16" if bf16 else "k_field_fwd_reg") + " (average of the coarse- and fine-pass launches)",
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "flop_per_launch": flop_launch},
-            "whole_path_tflops": round(value / world * flop_ray / 1e12, 2),
+            "whole_path_tflops": round(value / world * flop_ray / 1e12, 2),  # per GPU
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
