@@ -70,6 +70,9 @@ struct BfCtx {
 // Inline asm on purpose: hipcc treats a builtin LDS-DMA as a pending write to the whole LDS array and drains the load
 // queue (vmcnt(0)) in front of unrelated ds_reads; hidden from it, the loads are ordered by bf_sync's counted waits alone.
 __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_dst) {
+#ifdef NERF_TIMING_NO_DMA  // (timing experiments only)
+  return;
+#endif
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
@@ -107,8 +110,12 @@ __device__ __forceinline__ constexpr int bf_wait_count(int c) {
 // executed by every wave at fragment position BF_SYNC_POS of chunk c
 template <class S, int chunk>
 __device__ __forceinline__ void bf_sync(const BfCtx& c) {
+#ifndef NERF_TIMING_NO_WAIT                   // (timing experiments only)
   wait_vmcnt<bf_wait_count<S>(chunk)>();     // my pieces of chunk + 1 are in LDS ...
+#endif
+#ifndef NERF_TIMING_NO_BARRIER               // (timing experiments only: results are wrong without it)
   __builtin_amdgcn_s_barrier();              // ... and so are everybody's; everybody is past chunk - 1
+#endif
   asm volatile("" ::: "memory");             // no LDS read may be moved above the barrier by the compiler
   if (chunk + S::NS - 1 < S::NCHUNK) bf_dma_chunk<S>(c, chunk + S::NS - 1);  // into the slot of chunk - 1
 }
@@ -181,7 +188,9 @@ __device__ __forceinline__ void bf_segment(const BfCtx& c, u32x4 (&fr)[S::D], f3
     constexpr int cur = (P0 + f) & 1, oth = (P0 + f + 1) & 1;
     if constexpr (idx % BF_CHUNK == BF_SYNC_POS) bf_sync<S, idx / BF_CHUNK>(c);
     const u32x4 a = fr[idx % S::D];
+#ifndef NERF_TIMING_NO_FRAG  // (timing experiments only)
     if constexpr (idx + S::D < S::NFRAG) fr[idx % S::D] = bf_frag<S>(c, idx + S::D);
+#endif
     if constexpr (ks < KSA)
       acc[cur] = bf_mfma(a, inA[ks], acc[cur]);
     else

@@ -89,7 +89,11 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
       if (pi < 30) {
         const int cc = pi / 10, l = pi - 10 * cc;
         const float x = (cc == 0) ? p[0] : ((cc == 1) ? p[1] : p[2]);
+#ifdef NERF_TIMING_NO_SINCOS  // (timing experiments only)
+        sv = x; cv = x * 0.5f;
+#else
         sincos_phase(x * __uint_as_float(kFreqPointBits[l]), sv, cv);
+#endif
       }
       gp[ks][q] = pack2(sv, cv);
     }
@@ -102,7 +106,11 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
       if (pi < 12) {
         const int cc = pi / 4, l = pi - 4 * cc;
         const float x = (cc == 0) ? dw[0] : ((cc == 1) ? dw[1] : dw[2]);
+#ifdef NERF_TIMING_NO_SINCOS
+        sv = x; cv = x * 0.5f;
+#else
         sincos_phase(x * __uint_as_float(kFreqDirBits[l]), sv, cv);
+#endif
       }
       gd[ks][q] = pack2(sv, cv);
     }
@@ -132,6 +140,13 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   // epilogue of a ReLU layer: tile f -> packed k-steps 2f, 2f+1 of the next layer's input; training: + save + alive mask
   auto relu_to = [&](u32x4* out, int tensor = -1, int mlayer = -1) {
     return [&, out, tensor, mlayer](int f, const f32x16& A) {
+#ifdef NERF_TIMING_NO_EPI  // (timing experiments only: no conversion, half the values dropped)
+      if (f >= 0) {
+        for (int mh = 0; mh < 2; ++mh)
+          for (int q = 0; q < 4; ++q) out[2 * f + mh][q] = __float_as_uint(A[8 * mh + 2 * q]) & 0x3f803f80u;
+        return;
+      }
+#endif
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
