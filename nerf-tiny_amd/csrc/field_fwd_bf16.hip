@@ -11,7 +11,7 @@
 //     with a counted vmcnt, for its own two pieces) and frees the slot of chunk c-1 for the next load, while the fragment
 //     reads and MFMAs of chunk c continue on both sides of it;
 //   * output-tile-major order: one 16-register accumulator at a time runs over all k-steps of its tile, then is
-//     bias-free ReLU'd, rounded to bf16 pairwise (v_cvt_pk_bf16_f32 + v_pk_max_i16) and IS the next layer's B operand;
+//     ReLU'd and rounded to bf16 pairwise (v_cvt_pk_bf16_f32 + v_pk_max_i16) and IS the next layer's B operand;
 //     a layer's input and output live as 64 + 64 packed registers, so two waves fit on a SIMD and one wave's VALU work
 //     (encoding, conversions, heads) runs in the shadow of the other's MFMAs;
 //   * biases are fp32 accumulator start values read from LDS; sigma and colour heads are extra MFMA tiles (row 0 / rows
