@@ -56,6 +56,9 @@ enum {
                                           run on bf16 MFMA (bf16-rounded weights and layer inputs, fp32 accumulation and
                                           biases); rays, encodings, compositing, resampling and sort stay fp32.  NOT within
                                           1e-4 of the fp32 reference (about 1e-2); off by default */
+  NERF_HIP_WEIGHTS_UNCHANGED = 1 << 3, /* nerf_hip_forward only: the caller guarantees that weights24 hold the same values as in the
+                                          previous nerf_hip_forward call on this workspace with the same other flags, so the
+                                          packed weight image in the workspace is reused instead of rebuilt (rendering loops) */
 };
 
 /* status word bits (nerf_hip_read_status) */

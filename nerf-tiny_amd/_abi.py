@@ -15,6 +15,7 @@ NERF_HIP_ABI_VERSION = 2
 SAVE_FOR_BACKWARD = 1 << 0
 FORCE_TILE_KERNEL = 1 << 1
 BF16_MLP = 1 << 2
+WEIGHTS_UNCHANGED = 1 << 3
 STATUS_RESAMPLE_INDEX = 1 << 0
 
 _p = C.c_void_p
@@ -41,6 +42,10 @@ _PROTOS = {
 EXPORTS = tuple(_PROTOS)
 
 _lib = None
+
+#: bumped whenever the library writes network parameters behind torch's back (nerf_hip_adam_step): torch's own
+#: per-tensor ``_version`` counters do not see raw-pointer writes
+weights_epoch = [0]
 
 
 class NerfHipError(RuntimeError):

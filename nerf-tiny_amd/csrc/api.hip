@@ -49,6 +49,7 @@ int check_sizes(int B, int Nc, int Nf) {
 size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 
 WsLayout layout(int B, int Nc, int Nf, int flags) {
+  flags &= ~NERF_HIP_WEIGHTS_UNCHANGED;  // not a layout property
   WsLayout L;
   memset(&L, 0, sizeof(L));
   const size_t b = (size_t)B, N = (size_t)Nc + Nf;
@@ -186,7 +187,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   const Weights24 w = as_w24(weights24);
 
   HIP_TRY(hipMemsetAsync(at<void>(ws, L.status), 0, 256, st));
-  {
+  if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED)) {
     ProfScope ps(NERF_HIP_K_PACK, st);
     if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
     else HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));

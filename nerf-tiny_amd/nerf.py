@@ -78,6 +78,12 @@ class _RenderFn(torch.autograd.Function):
         flags = ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
                  | (_abi.BF16_MLP if getattr(model, "bf16_mlp", False) else 0))
         ws = model._workspace(B, flags)
+        # rendering loops: the packed weight image of the previous call on this workspace is still valid if no parameter has
+        # been written since (torch bumps a tensor's _version on every in-place update; FusedAdam, which writes through the
+        # C ABI, bumps _abi.weights_epoch)
+        stamp = (ws.data_ptr(), flags, _abi.weights_epoch[0]) + tuple((p.data_ptr(), p._version) for p in params)
+        call_flags = flags | (_abi.WEIGHTS_UNCHANGED if (not need_grad and getattr(model, "_packed_stamp", None) == stamp) else 0)
+        model._packed_stamp = stamp
         dev = row.device
         C_c = torch.empty(B, 3, dtype=torch.float32, device=dev)
         C_f = torch.empty(B, 3, dtype=torch.float32, device=dev)
@@ -85,7 +91,7 @@ class _RenderFn(torch.autograd.Function):
         wptr = _abi.ptr_array(params)
         _abi.check(_abi.lib().nerf_hip_forward(wptr, row.data_ptr(), col.data_ptr(), pb.data_ptr(), K9,
                                                ray0, B, Nc, Nf, LAST_DELTA, C_c.data_ptr(), C_f.data_ptr(),
-                                               ws.data_ptr(), ws.numel(), flags, stream))
+                                               ws.data_ptr(), ws.numel(), call_flags, stream))
         if need_grad:
             model._ws_generation += 1
             ctx.generation = model._ws_generation
@@ -129,6 +135,7 @@ class NeRFModel(nn.Module):
         self.bf16_mlp = False
         self._ws = {}
         self._ws_generation = 0
+        self._packed_stamp = None
 
     # ----- plumbing -------------------------------------------------------------------------
     def _workspace(self, B, flags):
@@ -145,6 +152,7 @@ class NeRFModel(nn.Module):
     def __getstate__(self):  # torch.save(model) (nerf.py:491) must not pickle the workspace
         d = dict(self.__dict__)
         d["_ws"] = {}
+        d["_packed_stamp"] = None
         return d
 
     def _params(self):

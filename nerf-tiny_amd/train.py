@@ -64,6 +64,7 @@ class FusedAdam(torch.optim.Optimizer):
         _abi.check(_abi.lib().nerf_hip_adam_step(_abi.ptr_array(ps), _abi.ptr_array([p.grad.contiguous() for p in ps]),
                                                  self._m.data_ptr(), self._v.data_ptr(), self._step, float(g["lr"]), float(b1),
                                                  float(b2), float(g["eps"]), torch.cuda.current_stream(dev).cuda_stream))
+        _abi.weights_epoch[0] += 1  # parameters changed without torch noticing: cached packed weight images are stale
         for p in ps:
             self.state[p]["step"] = torch.tensor(float(self._step))
         return None

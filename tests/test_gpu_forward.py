@@ -229,3 +229,34 @@ def test_render_rows_sharded_frame_with_tail(oracle, pkg, dev):
     with torch.no_grad():
         oc, of = oracle.render(w, row, col, pb, K, 64, 128)
     assert max_rel(out, of) < TOL
+
+
+def test_packed_weights_are_reused_only_while_unchanged(oracle, pkg, dev):
+    """rendering loops skip the weight re-packing (NERF_HIP_WEIGHTS_UNCHANGED); any parameter update -- through torch or
+    through the fused Adam kernel -- must invalidate the cached image"""
+    B, Nc, Nf = 64, 16, 32
+    row, col, pb, K, Ct = oracle.lego_inputs(B, seed=2)
+    w = oracle.make_weights(5)
+    m = pkg.NeRFModel(Nc, Nf, B)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    with torch.no_grad():
+        a = m(row, col, pb, K)
+        b = m(row, col, pb, K)  # second call: cached image
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        m.network.point_info.bias.add_(0.05)  # torch-visible update
+        c = m(row, col, pb, K)
+        assert not torch.equal(a[0], c[0])
+        w2 = {k: v.clone() for k, v in m.state_dict().items()}
+        oc, of = oracle.render({k: v.cpu() for k, v in w2.items()}, row, col, pb, K, Nc, Nf)
+        assert max_rel(c[0], oc) < TOL and max_rel(c[1], of) < TOL
+    # update through the C ABI (fused Adam): invisible to torch's version counters
+    opt = pkg.train.FusedAdam(list(m.network.parameters()), lr=1e-2)
+    Cc, Cf = m(row, col, pb, K)
+    m.ray_loss(Cc, Cf, Ct.to(dev)).backward()
+    opt.step()
+    with torch.no_grad():
+        d = m(row, col, pb, K)
+        od = oracle.render({k: v.detach().cpu() for k, v in m.state_dict().items()}, row, col, pb, K, Nc, Nf)
+    assert not torch.equal(d[0], c[0])
+    assert max_rel(d[0], od[0]) < TOL and max_rel(d[1], od[1]) < TOL
