@@ -254,7 +254,7 @@ def main():
                        f"ray-batch DP x{world} (one flat SUM all-reduce of 593,924 fp32 gradients per step)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None if bf16 else read_traffic(),
-                         "kernel": ("k_field_fwd_bf16" if bf16 else "k_field_fwd_reg") + " (average of the coarse- and fine-pass launches)",
+                         "kernel": (("k_field_fwd_bf16" if train else "k_field_fwd_bf16x") if bf16 else "k_field_fwd_reg") + " (average of the coarse- and fine-pass launches)",
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "flop_per_launch": flop_launch},
             "whole_path_tflops": round(value / world * flop_ray / 1e12, 2),  # per GPU

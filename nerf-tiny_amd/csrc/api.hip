@@ -184,12 +184,15 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool save = (flags & NERF_HIP_SAVE_FOR_BACKWARD) != 0;
   const bool bf16 = (flags & NERF_HIP_BF16_MLP) != 0;
+  // bf16 inference runs on the 16x16x32 MFMA form (field_fwd_bf16x.hip); NERF_HIP_FORCE_TILE_KERNEL selects the training form
+  const bool bf16x = bf16 && !save && !(flags & NERF_HIP_FORCE_TILE_KERNEL);
   const Weights24 w = as_w24(weights24);
 
   HIP_TRY(hipMemsetAsync(at<void>(ws, L.status), 0, 256, st));
   if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED)) {
     ProfScope ps(NERF_HIP_K_PACK, st);
-    if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
+    if (bf16 && bf16x) HIP_TRY(launch_pack_weights_bf16x(w, at<unsigned char>(ws, L.packed_bf), st));
+    else if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
     else HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
   }
 
@@ -231,7 +234,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     }
   }
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  auto field = [&](const FieldArgs& f) { return bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
+  auto field = [&](const FieldArgs& f) { return bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
   { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(field(fa)); }
 
   CoarseArgs ca;

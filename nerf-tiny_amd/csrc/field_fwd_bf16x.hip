@@ -1,0 +1,296 @@
+// field_fwd_bf16x.hip -- INFERENCE forward of the bf16-MLP field query on v_mfma_f32_16x16x32_bf16 (MI355X / gfx950).
+//
+// Same machinery and same arithmetic specification as field_fwd_bf16.hip (bf16_stream.h: LDS ring of 1-KiB weight
+// fragments, 8 waves x 32 samples, activations in registers, accumulator = next layer's operand), built on the 16x16x32
+// form of the bf16 MFMA: under an MFMA load this chip is power-limited, and on random operands the 16x16x32 form sustains
+// 2.09 PFLOP/s where the 32x32x16 form sustains 1.7-1.8 (scripts/micro/mfma_bf16_shapes.hip) -- same cycles per FLOP, a
+// higher clock.  What changes:
+//   * a fragment is 16 output features x 32 inputs (still 1 KiB, still one per 32 cycles of MFMA: it feeds TWO MFMAs, one
+//     per 16-sample half of the wave's 32 samples);
+//   * lane (n, q) = (lane & 15, lane >> 4) holds, for its two samples n and 16 + n, features 4q..4q+3 of every 16-feature
+//     accumulator tile (4 registers per tile and half); tiles 2s and 2s+1, ReLU'd and rounded pairwise, are the 8 k-slots
+//     of that lane for k-step s of the next layer -- slot j <-> input feature 32s + 16 (j >> 2) + 4q + (j & 3), which is the
+//     order the weight image stores;
+//   * biases: one 16-byte LDS read per tile (shared by both halves); sigma / colour heads: row 0 / rows 0..2 of an extra
+//     16-row tile, read from the lanes with q == 0.
+// Training keeps the 32x32x16 kernels (their save layout is what the chain and dW kernels read); the two forms round the
+// same bf16 operands but sum in a different order, so an inference and a training forward of the same batch agree to
+// fp32 rounding before the next bf16 rounding, not bit for bit.
+#include "bf16_stream.h"
+
+namespace nerf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// stream segments (16-row tiles x 32-wide k-steps), first fragment of each
+constexpr int BXS_L0 = 0;      // 16 tiles x 2
+constexpr int BXS_L1 = 32;     // 16 x 8, likewise L2, L3
+constexpr int BXS_L4 = 416;    // 16 x (8 hidden + 2 gamma_p)
+constexpr int BXS_L5 = 576;    // 16 x 8, likewise L6, L7
+constexpr int BXS_PI = 960;    // 17 x 8: point_info tiles 0..15, tile 16 row 0 = sigma_layer
+constexpr int BXS_DIR = 1096;  // 8 x (1 gamma_d + 8 feat)
+constexpr int BXS_COL = 1168;  // 1 x 4
+constexpr int BX_NFRAG = 1172;
+constexpr int BX_NCHUNK = (BX_NFRAG + BF_CHUNK - 1) / BF_CHUNK;  // 74 (the last chunk is padded)
+static_assert((size_t)BF_BIAS_BYTES + (size_t)BX_NCHUNK * BF_CHUNK * BF_FRAG_BYTES <= BF_IMAGE_BYTES, "shares the workspace region of the 32x32x16 image");
+// bias block: the float layout of the 32x32x16 image (bf16_common.h), addressed per 16 features
+constexpr int BXB_PI = 32 * BFB_PI, BXB_SIGMA = 32 * BFB_SIGMA, BXB_DIR = 32 * BFB_DIR, BXB_COL = 32 * BFB_COL;
+
+struct BxStream {
+  static constexpr int NFRAG = BX_NFRAG, NCHUNK = BX_NCHUNK, NS = BF_NS, RING_OFF = BF_BIAS_BYTES, D = BF_D;
+  static constexpr bool HAS_BIAS = true;
+  static constexpr int PROLOGUE_STORES = 0;
+  __device__ static constexpr int stores_before(int) { return 0; }
+};
+
+struct Acc2 { f32x4 c[2]; };  // one 16-feature tile for the two 16-sample halves
+
+__device__ __forceinline__ f32x4 bx_mfma(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// NT output tiles x (KSA + KSB) k-steps starting at fragment S0; inputs inA[half][k-step] then inB.  Tile f runs in
+// acc[(P0 + f) & 1]; the finished accumulators of tile f-1 are consumed by epi(f-1, .) right after the second k-step of tile
+// f (prev_epi: the last tile of the previous segment) and re-started at the bias of tile f+1 (bias float offset B0 + 16 f;
+// NEXT_B: of the next segment's tile 0, < 0: none).
+template <int S0, int NT, int KSA, int KSB, int B0, int P0, int NEXT_B, class Epi, class PrevEpi>
+__device__ __forceinline__ void bx_segment(const BfCtx& c, u32x4 (&fr)[BF_D], Acc2 (&acc)[2], const u32x4 (*inA)[8], const u32x4 (*inB)[8],
+                                           Epi&& epi, PrevEpi&& prev_epi) {
+  using S = BxStream;
+  constexpr int KS = KSA + KSB;
+  static_assert(KS >= 2, "segment too short for the deferred epilogue");
+  const int q = c.lane >> 4;
+  auto bias = [&](int off) {
+    const float4 v = *reinterpret_cast<const float4*>(c.lds + (off + 4 * q) * 4);
+    Acc2 a;
+    a.c[0] = f32x4{v.x, v.y, v.z, v.w};
+    a.c[1] = a.c[0];
+    return a;
+  };
+  static_for<NT * KS>([&](auto I) {
+    constexpr int f = I / KS, ks = I % KS, idx = S0 + I;
+    constexpr int cur = (P0 + f) & 1, oth = (P0 + f + 1) & 1;
+    if constexpr (idx % BF_CHUNK == BF_SYNC_POS) bf_sync<S, idx / BF_CHUNK>(c);
+    const u32x4 a = fr[idx % S::D];
+    if constexpr (idx + S::D < S::NFRAG) fr[idx % S::D] = bf_frag<S>(c, idx + S::D);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (ks < KSA)
+        acc[cur].c[h] = bx_mfma(a, inA[h][ks], acc[cur].c[h]);
+      else
+        acc[cur].c[h] = bx_mfma(a, inB[h][ks - KSA], acc[cur].c[h]);
+    }
+    if constexpr (ks == 1) {  // four MFMAs (64 cycles) after the previous tile's last one
+      if constexpr (f == 0)
+        prev_epi(acc[oth]);
+      else
+        epi(f - 1, acc[oth]);
+      if constexpr (f + 1 < NT)
+        acc[oth] = bias(B0 + 16 * (f + 1));
+      else if constexpr (NEXT_B >= 0)
+        acc[oth] = bias(NEXT_B);
+    }
+  });
+}
+
+__global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  using S = BxStream;
+  BfCtx c;
+  c.wimg = a.wbf;
+  c.lds = lds;
+  c.lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
+  c.lane = threadIdx.x & 63;
+  c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = c.lane, n = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * (BF_WG / 2) + c.wv * 32;
+
+  // ---- ordinary loads first: this lane's two samples (n and 16 + n of the wave's 32)
+  int ms[2];
+  bool valid[2];
+  float p[2][3], dw[2][3];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    ms[h] = m0 + 16 * h + n;
+    valid[h] = ms[h] < a.M;
+    const int mc = valid[h] ? ms[h] : a.M - 1;
+    const float* rf = a.rayf + (size_t)(mc / a.N) * RAYF;
+    sample_point(rf, a.t[mc], p[h]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dw[h][i] = rf[RF_DWRD + i];
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p[h][i]), "+v"(dw[h][i]));
+
+  bf_stream_start<S>(c);
+
+  // ---- encodings straight into B-operand registers: k-step s, slot pair (j, j+1) = (sin, cos) pair
+  // pi = 16s + 8 (j >> 2) + 2q + ((j >> 1) & 1), i.e. features 32s + 16 (j >> 2) + 4q + (j & 3)
+  u32x4 gp[2][8], gd[2][8];  // only [.][0..1] / [.][0] are used (the segment interface indexes [half][k-step])
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pi = 16 * s + 8 * (e >> 1) + 2 * q + (e & 1);
+        float sv = 0.f, cv = 0.f;
+        if (pi < 30) {
+          const int cc = pi / 10, l = pi - 10 * cc;
+          const float x = (cc == 0) ? p[h][0] : ((cc == 1) ? p[h][1] : p[h][2]);
+          sincos_phase(x * __uint_as_float(kFreqPointBits[l]), sv, cv);
+        }
+        gp[h][s][e] = pack2(sv, cv);
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pi = 8 * (e >> 1) + 2 * q + (e & 1);
+      float sv = 0.f, cv = 0.f;
+      if (pi < 12) {
+        const int cc = pi / 4, l = pi - 4 * cc;
+        const float x = (cc == 0) ? dw[h][0] : ((cc == 1) ? dw[h][1] : dw[h][2]);
+        sincos_phase(x * __uint_as_float(kFreqDirBits[l]), sv, cv);
+      }
+      gd[h][0][e] = pack2(sv, cv);
+    }
+  }
+
+  u32x4 fr[BF_D];
+  bf_stream_first<S>(c, fr);
+
+  u32x4 X[2][8], Y[2][8];
+  Acc2 acc[2];
+  {
+    const float4 v = *reinterpret_cast<const float4*>(lds + (4 * q) * 4);
+    acc[0].c[0] = f32x4{v.x, v.y, v.z, v.w};
+    acc[0].c[1] = acc[0].c[0];
+  }
+  // epilogue of a ReLU layer: tile f (16 features) -> slots 2 (f & 1), 2 (f & 1) + 1 of k-step f >> 1 of the next layer
+  auto relu_to = [&](u32x4 (*out)[8]) {
+    return [out](int f, const Acc2& A) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        out[h][f >> 1][2 * (f & 1) + 0] = pack2_relu(A.c[h][0], A.c[h][1]);
+        out[h][f >> 1][2 * (f & 1) + 1] = pack2_relu(A.c[h][2], A.c[h][3]);
+      }
+    };
+  };
+  auto last_of = [](auto epi, int f) { return [epi, f](const Acc2& A) { epi(f, A); }; };
+  auto nothing = [](const Acc2&) {};
+  auto nothing_f = [](int, const Acc2&) {};
+
+  // ---- layers 0..7 (nerf.py:104-112)
+  bx_segment<BXS_L0, 16, 2, 0, 0 * 256, 0, 1 * 256>(c, fr, acc, gp, nullptr, relu_to(X), nothing);
+  bx_segment<BXS_L1, 16, 8, 0, 1 * 256, 0, 2 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<BXS_L1 + 128, 16, 8, 0, 2 * 256, 0, 3 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<BXS_L1 + 256, 16, 8, 0, 3 * 256, 0, 4 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<BXS_L4, 16, 8, 2, 4 * 256, 0, 5 * 256>(c, fr, acc, Y, gp, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<BXS_L5, 16, 8, 0, 5 * 256, 0, 6 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<BXS_L5 + 128, 16, 8, 0, 6 * 256, 0, 7 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<BXS_L5 + 256, 16, 8, 0, 7 * 256, 0, BXB_PI>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  // ---- point_info (no activation) + sigma head (tile 16, row 0)  (nerf.py:94, 113-115)
+  float spre[2] = {0.f, 0.f};
+  auto pi_epi = [&](int f, const Acc2& A) {
+    if (f < 16) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        X[h][f >> 1][2 * (f & 1) + 0] = pack2(A.c[h][0], A.c[h][1]);
+        X[h][f >> 1][2 * (f & 1) + 1] = pack2(A.c[h][2], A.c[h][3]);
+      }
+    } else {
+      spre[0] = A.c[0][0];
+      spre[1] = A.c[1][0];
+    }
+  };
+  // the bias of the sigma tile sits at BXB_SIGMA, not behind point_info's 16 tiles: tile 16 is restarted by hand below
+  bx_segment<BXS_PI, 16, 8, 0, BXB_PI, 0, BXB_SIGMA>(c, fr, acc, Y, nullptr, pi_epi, last_of(relu_to(Y), 15));
+  bx_segment<BXS_PI + 128, 1, 8, 0, BXB_SIGMA, 0, BXB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(pi_epi, 15));
+  // ---- dir_info on cat(gamma_d, feat), ReLU (nerf.py:117-118); its first tile also retires the sigma tile
+  bx_segment<BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, X, relu_to(Y), last_of(pi_epi, 16));
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (valid[h] && q == 0) a.sigma[ms[h]] = fabsf(spre[h]);
+  // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
+  bx_segment<BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 7));
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (valid[h] && q == 0) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) a.rgb[(size_t)ms[h] * 3 + ch] = 1.0f / (1.0f + expf(-acc[1].c[h][ch]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight image: fragment (tile T, k-step s), lane (i, q), slot j = W[16T + i][32s + 16 (j >> 2) + 4q + (j & 3)]
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bx_weight(const Weights24& w, int frag, int i, int kk /* input feature inside the k-step */) {
+  if (frag < BXS_L1) {  // L0
+    const int T = frag / 2, s = frag % 2, k = 32 * s + kk;
+    return k < POINT_DIM ? w.p[0][(size_t)(16 * T + i) * POINT_DIM + k] : 0.f;
+  }
+  if (frag < BXS_L4) {  // L1..L3
+    const int r = frag - BXS_L1, l = 1 + r / 128, x = r % 128, T = x / 8, s = x % 8;
+    return w.p[2 * l][(size_t)(16 * T + i) * WIDTH + 32 * s + kk];
+  }
+  if (frag < BXS_L5) {  // L4: [256][316] = cat(hidden, gamma_p)
+    const int x = frag - BXS_L4, T = x / 10, s = x % 10, k = 32 * s + kk;
+    return (k < WIDTH + POINT_DIM) ? w.p[8][(size_t)(16 * T + i) * (WIDTH + POINT_DIM) + k] : 0.f;
+  }
+  if (frag < BXS_PI) {  // L5..L7
+    const int r = frag - BXS_L5, l = 5 + r / 128, x = r % 128, T = x / 8, s = x % 8;
+    return w.p[2 * l][(size_t)(16 * T + i) * WIDTH + 32 * s + kk];
+  }
+  if (frag < BXS_DIR) {  // point_info, then the sigma tile
+    const int x = frag - BXS_PI, T = x / 8, s = x % 8, k = 32 * s + kk;
+    if (T < 16) return w.p[W_PI][(size_t)(16 * T + i) * WIDTH + k];
+    return i == 0 ? w.p[W_SIGMA][k] : 0.f;
+  }
+  if (frag < BXS_COL) {  // dir_info: [128][280] = cat(gamma_d (24), feat)
+    const int x = frag - BXS_DIR, T = x / 9, s = x % 9;
+    if (s == 0) return kk < DIR_DIM ? w.p[W_DIR][(size_t)(16 * T + i) * (WIDTH + DIR_DIM) + kk] : 0.f;
+    return w.p[W_DIR][(size_t)(16 * T + i) * (WIDTH + DIR_DIM) + DIR_DIM + 32 * (s - 1) + kk];
+  }
+  if (frag < BX_NFRAG) {  // colour head
+    const int s = frag - BXS_COL, k = 32 * s + kk;
+    return i < 3 ? w.p[W_COLOR][(size_t)i * HALF + k] : 0.f;
+  }
+  return 0.f;  // padding of the last chunk
+}
+
+// the bias block is the 32x32x16 image's (same float layout); only the fragments differ
+__global__ __launch_bounds__(256) void k_pack_weights_bf16x(const Weights24 w, unsigned char* __restrict__ img) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= BX_NCHUNK * BF_CHUNK * 64) return;
+  const int frag = gid >> 6, lane = gid & 63, i = lane & 15, q = lane >> 4;
+  u32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {  // slots 2e, 2e + 1
+    const int kk = 16 * (e >> 1) + 4 * q + 2 * (e & 1);
+    v[e] = pack2(bx_weight(w, frag, i, kk), bx_weight(w, frag, i, kk + 1));
+  }
+  *reinterpret_cast<u32x4*>(img + BF_BIAS_BYTES + (size_t)frag * BF_FRAG_BYTES + lane * 16) = v;
+}
+
+hipError_t launch_pack_weights_bf16x(const Weights24& w, unsigned char* img, hipStream_t st) {
+  hipError_t e = launch_pack_weights_bf16(w, img, st);  // bias block (and the 32x32x16 fragments, overwritten next)
+  if (e != hipSuccess) return e;
+  const int threads = BX_NCHUNK * BF_CHUNK * 64;
+  hipLaunchKernelGGL(k_pack_weights_bf16x, dim3((threads + 255) / 256), dim3(256), 0, st, w, img);
+  return hipGetLastError();
+}
+
+hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_bf16x), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
+  hipLaunchKernelGGL(k_field_fwd_bf16x, dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace nerf
