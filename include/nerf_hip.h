@@ -51,7 +51,9 @@ enum {
 enum {
   NERF_HIP_SAVE_FOR_BACKWARD = 1 << 0, /* forward keeps activations in the workspace for nerf_hip_backward */
   NERF_HIP_FORCE_TILE_KERNEL = 1 << 1, /* inference: use the LDS-tile field kernel instead of the register-resident one
-                                          (same results up to summation order; for A/B measurements and tests) */
+                                          (same results up to summation order; for A/B measurements and tests).  With
+                                          NERF_HIP_BF16_MLP: inference on the 32x32x16 kernel that training uses instead of the
+                                          16x16x32 one (bit-identical to the forward half of a training call) */
   NERF_HIP_BF16_MLP = 1 << 2,          /* BASELINE.json cfg3 "bf16 MLP / fp32 composite": the 12 linear layers of the field MLP
                                           run on bf16 MFMA (bf16-rounded weights and layer inputs, fp32 accumulation and
                                           biases); rays, encodings, compositing, resampling and sort stay fp32.  NOT within
