@@ -192,6 +192,24 @@ def test_bf16_ragged_and_maximum_sizes_forward(oracle, pkg, dev, B, Nc, Nf):
     assert max_rel(Cf, ef) < 3e-2, max_rel(Cf, ef)
 
 
+def test_bf16_inference_forms(oracle, pkg, dev):
+    """inference runs on the 16x16x32 MFMA form, training on 32x32x16: the two agree to summation order (a few flipped
+    bf16 roundings); with force_tile_kernel the inference uses the training form and equals a training forward bit for bit"""
+    g = load_golden("cfg1_lego_crop32")
+    row, col, pb, K, _ = golden_inputs(g)
+    Nc, Nf, B = int(g["Nc"]), int(g["Nf"]), row.shape[0]
+    params, _ = _params_dev(oracle, int(g["seed"]), bool(g["sharp"]), dev)
+    m = _bf16_model(pkg, params, Nc, Nf, B, dev)
+    Tc, Tf = m(row.to(dev), col.to(dev), pb.to(dev), K)          # training form (grad enabled)
+    with torch.no_grad():
+        Ic, If = m(row.to(dev), col.to(dev), pb.to(dev), K)      # 16x16x32
+        m.force_tile_kernel = True
+        Fc, Ff = m(row.to(dev), col.to(dev), pb.to(dev), K)      # 32x32x16, inference variant
+    assert torch.equal(Fc, Tc.detach()) and torch.equal(Ff, Tf.detach())
+    assert not torch.equal(Ic, Fc)
+    assert max_rel(Ic, Fc) < 2e-3 and max_rel(If, Ff) < 1e-2
+
+
 def test_bf16_ragged_sizes(oracle, pkg, dev):
     """pass sizes that are not multiples of the 256-sample workgroup / 32-sample wave block (B*Nc = 132, B*Nf = 220):
     the padded lanes must contribute nothing to any gradient"""
