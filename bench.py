@@ -260,6 +260,16 @@ def main():
             "whole_path_tflops": round(value / world * flop_ray / 1e12, 2),  # per GPU
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
         }
+        if bf16 and train and "bwd_dw" in prof:
+            # the bf16 train step is HBM-bound; its dominant phase is the weight-gradient passes: 318 KiB of
+            # bf16 operands per 32-sample wave block (11 passes: G and X pieces of bf16_common.h), read once each
+            wb = ((b_local * NC + 255) // 256 + (b_local * NF + 255) // 256) * 8
+            dw_bytes = 318 * 1024 * wb
+            dw_ms = prof["bwd_dw"][0] / max(prof["bwd_dw"][1], 1)
+            out["roofline"] = {"bound": "hbm", "achieved": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(dw_bytes / (dw_ms * 1e-3) / 8e12, 4), "traffic": None,
+                               "kernel": "k_dw_bf16 (the 11 weight-gradient passes + slab reduces of one step)",
+                               "avg_launch_ms": round(dw_ms, 4), "launches": prof["bwd_dw"][1], "bytes_per_launch": dw_bytes}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             out["cpu_baseline"] = cb
