@@ -18,7 +18,7 @@ constexpr int BB_NS = 5;
 constexpr int BB_MASK_BYTES = 8 * BM_LAYERS * 1024;  // per workgroup: wave w, layer l at (w * 9 + l) * 1024
 constexpr int BB_LDS_BYTES = BB_MASK_BYTES + BB_NS * BF_CHUNK * BF_FRAG_BYTES;
 
-struct BwdTiles { int s0, nft, ks, stores; };
+struct BwdTiles { int s0, nft, ks, last_stores; };  // a layer's gradient pieces go out in one burst with its last tile
 
 template <bool FINE>
 struct BwdStream {
@@ -29,16 +29,16 @@ struct BwdStream {
   static constexpr int PROLOGUE_STORES = 2;  // the dz / dspre fragment and its zero partner
   static constexpr int L3T = BBS_L3T;
   static constexpr BfStoreTable<NFRAG> make() {
-    const BwdTiles tiles[] = {{BBS_COLT, 4, 4, 2},       {BBS_DIRT, 8, 8, 2},       {BBS_PIT, 8, 17, 2},      {BBS_L7T, 8, 16, 2},
-                              {BBS_L7T + 128, 8, 16, 2}, {BBS_L7T + 256, 8, 16, 2}, {BBS_L4T, 8, 16, 2},      {L3T, 8, 16, 2},
-                              {L3T + 128, 8, 16, 2},     {L3T + 256, 8, 16, 2}};  // the d gamma_p tiles store nothing
+    const BwdTiles tiles[] = {{BBS_COLT, 4, 4, 8},        {BBS_DIRT, 8, 8, 16},       {BBS_PIT, 8, 17, 16},     {BBS_L7T, 8, 16, 16},
+                              {BBS_L7T + 128, 8, 16, 16}, {BBS_L7T + 256, 8, 16, 16}, {BBS_L4T, 8, 16, 16},     {L3T, 8, 16, 16},
+                              {L3T + 128, 8, 16, 16},     {L3T + 256, 8, 16, 16}};  // the d gamma_p tiles store nothing
     BfStoreTable<NFRAG> t{};
     int ev[NFRAG + 64] = {};
     for (const BwdTiles& g : tiles)
-      for (int f = 0; f < g.nft; ++f) {
-        int e = g.s0 + (f + 1) * g.ks + BF_EPI_POS;
+      {
+        int e = g.s0 + g.nft * g.ks + BF_EPI_POS;  // epilogue of the segment's last tile
         // (an epilogue deferred past the end of the coarse stream runs after the last sync point)
-        ev[e < NFRAG + 64 ? e : NFRAG + 63] += g.stores;
+        ev[e < NFRAG + 64 ? e : NFRAG + 63] += g.last_stores;
       }
     int run = 0;
     for (int i = 0; i <= NFRAG; ++i) {
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
   acc[0] = zero;
   const uint16_t* const mk = reinterpret_cast<const uint16_t*>(lds + c.wv * BM_LAYERS * 1024) + lane;
   // epilogue: d(input) tile f -> (mask with the ReLU bits of `mlayer`) -> packed k-steps 2f, 2f+1 of the next GEMM + store
-  auto grad_to = [&](u32x4* out, int tensor, int mlayer) {
-    return [&, out, tensor, mlayer](int f, const f32x16& A) {
+  auto grad_to = [&](u32x4* out, int tensor, int mlayer, int ntiles = 8) {
+    return [&, out, tensor, mlayer, ntiles](int f, const f32x16& A) {
       f32x16 D = A;
       if (mlayer >= 0) {
         const int bits = mk[(mlayer * 8 + f) * 64];
@@ -123,17 +123,20 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[2 * f + mh][q] = pack2(D[8 * mh + 2 * q], D[8 * mh + 2 * q + 1]);
-      grad_piece(tensor, 2 * f, out[2 * f]);
-      grad_piece(tensor, 2 * f + 1, out[2 * f + 1]);
+      if (f == ntiles - 1) {  // the whole gradient tensor of this wave block in one contiguous burst
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          if (ks < 2 * ntiles) grad_piece(tensor, ks, out[ks]);
+      }
     };
   };
   auto last_of = [](auto epi, int f) { return [epi, f](const f32x16& A) { epi(f, A); }; };
   auto nothing = [](const f32x16&) {};
 
   // colour head: dc = W_color^T dz, through c's ReLU -> dpre_dir
-  bf_segment<S, BBS_COLT, 4, 4, 0, -1, 0, -1>(c, fr, acc, zin, nullptr, grad_to(Y, BG_D, 8), nothing);
+  bf_segment<S, BBS_COLT, 4, 4, 0, -1, 0, -1>(c, fr, acc, zin, nullptr, grad_to(Y, BG_D, 8, 4), nothing);
   // dir_info: dfeat = W_dir[:, 24:]^T dpre_dir (point_info has no activation)
-  bf_segment<S, BBS_DIRT, 8, 8, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_PI, -1), last_of(grad_to(Y, BG_D, 8), 3));
+  bf_segment<S, BBS_DIRT, 8, 8, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_PI, -1), last_of(grad_to(Y, BG_D, 8, 4), 3));
   // point_info + sigma head: dh7 = W_PI^T dfeat + w_sigma dspre, through h7's ReLU
   bf_segment<S, BBS_PIT, 8, 16, 1, -1, 0, -1>(c, fr, acc, X, zin, grad_to(Y, BG_L0 + 7, 7), last_of(grad_to(X, BG_PI, -1), 7));
   bf_segment<S, BBS_L7T, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 6, 6), last_of(grad_to(Y, BG_L0 + 7, 7), 7));

@@ -21,16 +21,18 @@
 namespace nerf {
 
 // ---- store schedule of the training variant (see bf16_stream.h): stores per tile epilogue ------------------------------
-struct FwdTiles { int s0, nft, ks, stores; };
+// The mask word of a tile goes out with the tile; the 16 (8) pieces of a layer's output go out in ONE burst with its last
+// tile -- 16 KiB contiguous per wave instead of 1-KiB pieces spread over the layer (DRAM page locality of the write stream).
+struct FwdTiles { int s0, nft, ks, stores, last_extra; };
 constexpr FwdTiles kFwdTiles[] = {
-    {BFS_L0, 8, 4, 3},        {BFS_L1, 8, 16, 3},       {BFS_L1 + 128, 8, 16, 3}, {BFS_L1 + 256, 8, 16, 3}, {BFS_L4, 8, 20, 3},
-    {BFS_L5, 8, 16, 3},       {BFS_L5 + 128, 8, 16, 3}, {BFS_L5 + 256, 8, 16, 3}, {BFS_PI, 8, 16, 2},       {BFS_PI + 128, 1, 16, 0},
-    {BFS_DIR, 4, 18, 3},      {BFS_COL, 1, 8, 0}};
+    {BFS_L0, 8, 4, 1, 16},        {BFS_L1, 8, 16, 1, 16},       {BFS_L1 + 128, 8, 16, 1, 16}, {BFS_L1 + 256, 8, 16, 1, 16},
+    {BFS_L4, 8, 20, 1, 16},       {BFS_L5, 8, 16, 1, 16},       {BFS_L5 + 128, 8, 16, 1, 16}, {BFS_L5 + 256, 8, 16, 1, 16},
+    {BFS_PI, 8, 16, 0, 16},       {BFS_PI + 128, 1, 16, 0, 0},  {BFS_DIR, 4, 18, 1, 8},       {BFS_COL, 1, 8, 0, 0}};
 constexpr BfStoreTable<BF_NFRAG> make_fwd_store_table() {
   BfStoreTable<BF_NFRAG> t{};
   int ev[BF_NFRAG + 64] = {};
   for (const FwdTiles& g : kFwdTiles)
-    for (int f = 0; f < g.nft; ++f) ev[g.s0 + (f + 1) * g.ks + BF_EPI_POS] += g.stores;
+    for (int f = 0; f < g.nft; ++f) ev[g.s0 + (f + 1) * g.ks + BF_EPI_POS] += g.stores + (f == g.nft - 1 ? g.last_extra : 0);
   int run = 0;
   for (int i = 0; i <= BF_NFRAG; ++i) {
     t.cum[i] = run;  // events strictly before step i
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   f32x16 acc[2];
   acc[0] = bf_bias_tile(c, BFB_L0);
   // epilogue of a ReLU layer: tile f -> packed k-steps 2f, 2f+1 of the next layer's input; training: + save + alive mask
-  auto relu_to = [&](u32x4* out, int tensor = -1, int mlayer = -1) {
-    return [&, out, tensor, mlayer](int f, const f32x16& A) {
+  auto relu_to = [&](u32x4* out, int tensor = -1, int mlayer = -1, int ntiles = 8) {
+    return [&, out, tensor, mlayer, ntiles](int f, const f32x16& A) {
 #ifdef NERF_TIMING_NO_EPI  // (timing experiments only: no conversion, half the values dropped)
       if (f >= 0) {
         for (int mh = 0; mh < 2; ++mh)
@@ -152,9 +154,12 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[2 * f + mh][q] = pack2_relu(A[8 * mh + 2 * q], A[8 * mh + 2 * q + 1]);
       if constexpr (SAVE) {
-        save_piece(tensor, 2 * f, out[2 * f]);
-        save_piece(tensor, 2 * f + 1, out[2 * f + 1]);
         mkl[(((size_t)mlayer * a.wb_tot + wb) * 8 + f) * 64] = (uint16_t)alive_bits(A);
+        if (f == ntiles - 1) {  // the layer's output is complete: one contiguous burst
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks)
+            if (ks < 2 * ntiles) save_piece(tensor, ks, out[ks]);
+        }
       }
     };
   };
@@ -180,8 +185,10 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) X[2 * f + mh][q] = pack2(A[8 * mh + 2 * q], A[8 * mh + 2 * q + 1]);
       if constexpr (SAVE) {
-        save_piece(BS_FEAT, 2 * f, X[2 * f]);
-        save_piece(BS_FEAT, 2 * f + 1, X[2 * f + 1]);
+        if (f == 7) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) save_piece(BS_FEAT, ks, X[ks]);
+        }
       }
     } else {
       spre = A[0];
@@ -189,13 +196,13 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   };
   bf_segment<S, BFS_PI, 9, 16, 0, BFB_PI, 0, BFB_DIR>(c, fr, acc, Y, nullptr, pi_epi, last_of(relu_to(Y, BS_H0 + 7, 7), 7));
   // ---- dir_info on cat(gamma_d, feat), ReLU (nerf.py:117-118); its first tile also retires the sigma tile
-  bf_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd, X, relu_to(Y, BS_C, 8), last_of(pi_epi, 8));
+  bf_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd, X, relu_to(Y, BS_C, 8, 4), last_of(pi_epi, 8));
   if (valid && h == 0) {
     a.sigma[m] = fabsf(spre);
     if (SAVE) a.spre[a.row0 + m] = spre;
   }
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
-  bf_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y, BS_C, 8), 3));
+  bf_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y, BS_C, 8, 4), 3));
   if (valid && h == 0) {
     a.rgb[(size_t)m * 3 + 0] = 1.0f / (1.0f + expf(-acc[1][0]));
     a.rgb[(size_t)m * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
