@@ -63,7 +63,7 @@ constexpr int BG_L0 = 0, BG_PI = 8, BG_D = 9, BG_Z = 10, NBG = 11;  // BG_Z: fea
 __host__ __device__ constexpr int bg_ks(int t) { return t <= BG_PI ? 16 : t == BG_D ? 8 : 2; }  // BG_Z: 2nd piece = zeros
 __host__ __device__ constexpr int bg_cum(int t) { int o = 0; for (int i = 0; i < t; ++i) o += bg_ks(i); return o; }
 constexpr int BG_TOTAL_KS = bg_cum(NBG);  // 154
-// ReLU "alive" masks: u16 [9 layers: h0..h7, c][wb_tot][8 tiles][64 lanes], bit 15-r = accumulator register r >= +0
+// ReLU "alive" masks: u16 [9 layers: h0..h7, c][wb_tot][64 lanes][8 tiles], bit 15-r = accumulator register r >= +0
 constexpr int BM_LAYERS = 9;
 
 // bias tiles (32 floats each) in the bias block

@@ -108,13 +108,13 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
   f32x16 acc[2];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   acc[0] = zero;
-  const uint16_t* const mk = reinterpret_cast<const uint16_t*>(lds + c.wv * BM_LAYERS * 1024) + lane;
+  const uint16_t* const mk = reinterpret_cast<const uint16_t*>(lds + c.wv * BM_LAYERS * 1024) + lane * 8;  // [layer][lane][8 tiles]
   // epilogue: d(input) tile f -> (mask with the ReLU bits of `mlayer`) -> packed k-steps 2f, 2f+1 of the next GEMM + store
   auto grad_to = [&](u32x4* out, int tensor, int mlayer, int ntiles = 8) {
     return [&, out, tensor, mlayer, ntiles](int f, const f32x16& A) {
       f32x16 D = A;
       if (mlayer >= 0) {
-        const int bits = mk[(mlayer * 8 + f) * 64];
+        const int bits = mk[mlayer * 512 + f];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           D[r] = __uint_as_float(__float_as_uint(A[r]) & (unsigned)__builtin_amdgcn_sbfe(bits, 15 - r, 1));

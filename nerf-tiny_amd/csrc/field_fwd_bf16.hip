@@ -21,13 +21,13 @@
 namespace nerf {
 
 // ---- store schedule of the training variant (see bf16_stream.h): stores per tile epilogue ------------------------------
-// The mask word of a tile goes out with the tile; the 16 (8) pieces of a layer's output go out in ONE burst with its last
-// tile -- 16 KiB contiguous per wave instead of 1-KiB pieces spread over the layer (DRAM page locality of the write stream).
+// The 16 (8) pieces of a layer's output and its 8 (4) mask words (one 16-byte store per lane) go out in ONE burst with the
+// layer's last tile -- 17 KiB contiguous per wave instead of pieces spread over the layer (DRAM page locality of the writes).
 struct FwdTiles { int s0, nft, ks, stores, last_extra; };
 constexpr FwdTiles kFwdTiles[] = {
-    {BFS_L0, 8, 4, 1, 16},        {BFS_L1, 8, 16, 1, 16},       {BFS_L1 + 128, 8, 16, 1, 16}, {BFS_L1 + 256, 8, 16, 1, 16},
-    {BFS_L4, 8, 20, 1, 16},       {BFS_L5, 8, 16, 1, 16},       {BFS_L5 + 128, 8, 16, 1, 16}, {BFS_L5 + 256, 8, 16, 1, 16},
-    {BFS_PI, 8, 16, 0, 16},       {BFS_PI + 128, 1, 16, 0, 0},  {BFS_DIR, 4, 18, 1, 8},       {BFS_COL, 1, 8, 0, 0}};
+    {BFS_L0, 8, 4, 0, 17},        {BFS_L1, 8, 16, 0, 17},       {BFS_L1 + 128, 8, 16, 0, 17}, {BFS_L1 + 256, 8, 16, 0, 17},
+    {BFS_L4, 8, 20, 0, 17},       {BFS_L5, 8, 16, 0, 17},       {BFS_L5 + 128, 8, 16, 0, 17}, {BFS_L5 + 256, 8, 16, 0, 17},
+    {BFS_PI, 8, 16, 0, 16},       {BFS_PI + 128, 1, 16, 0, 0},  {BFS_DIR, 4, 18, 0, 9},       {BFS_COL, 1, 8, 0, 0}};
 constexpr BfStoreTable<BF_NFRAG> make_fwd_store_table() {
   BfStoreTable<BF_NFRAG> t{};
   int ev[BF_NFRAG + 64] = {};
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   // lanes beyond the pass (they hold a copy of the last sample): the counted waits rely on the stores being issued
   const int wb = a.wb0 + blockIdx.x * (BF_WG / 64) + c.wv;
   unsigned char* const svl = SAVE ? a.bsave + lane * 16 : nullptr;
-  uint16_t* const mkl = SAVE ? a.bmask + lane : nullptr;
+  unsigned char* const mkl = SAVE ? reinterpret_cast<unsigned char*>(a.bmask) + lane * 16 : nullptr;
+  unsigned mw[4] = {0u, 0u, 0u, 0u};
   auto save_piece = [&](int tensor, int ks, const u32x4& v) {
     *reinterpret_cast<u32x4*>(svl + ((size_t)a.wb_tot * bs_cum(tensor) + (size_t)wb * bs_ks(tensor) + ks) * BF_FRAG_BYTES) = v;
   };
@@ -154,8 +155,14 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[2 * f + mh][q] = pack2_relu(A[8 * mh + 2 * q], A[8 * mh + 2 * q + 1]);
       if constexpr (SAVE) {
-        mkl[(((size_t)mlayer * a.wb_tot + wb) * 8 + f) * 64] = (uint16_t)alive_bits(A);
+        // mask words of the layer's tiles, two per register: u16 [layer][wave block][lane][8 tiles]
+        if (f & 1)
+          mw[f >> 1] |= alive_bits(A) << 16;
+        else
+          mw[f >> 1] = alive_bits(A);
         if (f == ntiles - 1) {  // the layer's output is complete: one contiguous burst
+          u32x4 mv = {mw[0], mw[1], ntiles > 4 ? mw[2] : 0u, ntiles > 4 ? mw[3] : 0u};
+          *reinterpret_cast<u32x4*>(mkl + ((size_t)mlayer * a.wb_tot + wb) * 1024) = mv;
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks)
             if (ks < 2 * ntiles) save_piece(tensor, ks, out[ks]);
