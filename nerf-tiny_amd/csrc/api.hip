@@ -382,15 +382,19 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     // layer 0: X = gamma_p
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
     HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1], st));
-    for (int l = 1; l <= 7; ++l) {
-      if (l == 4) {  // one pass over dpre4 for both column groups of the [256][316] matrix: X = [h3 | gamma_p]
-        HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
-        HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9], st));
-      } else {
-        HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + l), 16, X(BS_H0 + l - 1), 16, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
-        HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 256, 0, 256, 0, WIDTH, dw[2 * l], WIDTH, 0, dw[2 * l + 1], st));
-      }
+    {  // layers 1, 2, 3, 5, 6, 7: six 256 x 256 products in ONE launch (42 workgroups each: a sixth of the slab traffic)
+      static const int layers[6] = {1, 2, 3, 5, 6, 7};
+      const unsigned char* Gs[6];
+      const unsigned char* Xs[6];
+      for (int k = 0; k < 6; ++k) { Gs[k] = Gt(BG_L0 + layers[k]); Xs[k] = X(BS_H0 + layers[k] - 1); }
+      HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st));
+      for (int k = 0; k < 6; ++k)
+        HIP_TRY(launch_dw_bf16_reduce(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dw[2 * layers[k]], WIDTH, 0,
+                                      dw[2 * layers[k] + 1], st));
     }
+    // layer 4: one pass over dpre4 for both column groups of the [256][316] matrix: X = [h3 | gamma_p]
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9], st));
     // point_info, and in the same pass over h7 the sigma head: row 3 of h7^T (dz, dspre)
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_PI), 16, X(BS_H0 + 7), 16, nullptr, 0, Gt(BG_Z), wb_tot, slabs, &ns, st));
     HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 288, 256, 0, 256, 0, WIDTH, dw[W_PI], WIDTH, 0, dw[B_PI], st));

@@ -17,6 +17,8 @@
 // The kernel is HBM-bound by construction (1 KiB of operands per 128 kFLOP): it is paced by the ring, not by the MFMAs.
 #include "bf16_stream.h"
 
+#include <string.h>
+
 namespace nerf {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -25,14 +27,17 @@ typedef s16x4 __attribute__((address_space(3)))* lds_s16x4_p;
 constexpr int DWB_WGS = 256;
 
 struct DwBfArgs {
-  const unsigned char* G;   // start of the gradient tensor (fragment layout), g_ks pieces per wave block
-  const unsigned char* X1;  // input tensor(s): the i index runs over X1's x1_ks pieces, then X2's (2 * NIT - x1_ks)
-  const unsigned char* X2;
+  // ngemm same-shaped products share one launch: workgroup b works on product b % ngemm with the samples split over the
+  // gridDim.x / ngemm workgroups of that product -- all CUs busy with 1/ngemm of the slabs per product
+  const unsigned char* G[6];   // start of the gradient tensor (fragment layout), g_ks pieces per wave block
+  const unsigned char* X1[6];  // input tensor(s): the i index runs over X1's x1_ks pieces, then X2's (2 * NIT - x1_ks)
+  const unsigned char* X2;     // (single products only)
+  int ngemm;
   const unsigned char* Z;   // HAS_Z: a second, 2-piece gradient tensor whose product with X is formed as well (X^T Z)
   int g_ks, o_tiles;        // o_tiles = output row tiles (waves w >= o_tiles only help loading)
   int x1_ks;
   int wb_tot;
-  float* slabs;             // [gridDim.x][o_tiles*32 (+32 with Z)][NIT*32 + 1]  (last column: sum of G over the samples)
+  float* slabs;             // [product][workgroup][o_tiles*32 (+32 with Z)][NIT*32 + 1]  (last column: sum of G over the samples)
 };
 
 // LDS unit (16 bytes) of (piece ks, half h, sample s) inside a tensor block: the sample index is XOR-swizzled
@@ -72,8 +77,11 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
-  const int per = (a.wb_tot + gridDim.x - 1) / gridDim.x;
-  const int b_lo = blockIdx.x * per, b_hi = min(a.wb_tot, b_lo + per);
+  const int gi = blockIdx.x % a.ngemm, wg = blockIdx.x / a.ngemm, nwg = gridDim.x / a.ngemm;
+  const unsigned char* const gG = a.G[gi];
+  const unsigned char* const gX1 = a.X1[gi];
+  const int per = (a.wb_tot + nwg - 1) / nwg;
+  const int b_lo = wg * per, b_hi = min(a.wb_tot, b_lo + per);
   const int nb = b_hi - b_lo;
   const int gks = a.g_ks, x1 = a.x1_ks, total = gks + XKS + (HAS_Z ? 2 : 0);
   const bool worker = wv < a.o_tiles, zworker = HAS_Z && wv < NIT;
@@ -99,11 +107,11 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
       int ks, dst;
       if (pc < gks) {
         ks = pc; dst = ks;
-        src = a.G + ((size_t)wb * gks + ks) * BF_FRAG_BYTES;
+        src = gG + ((size_t)wb * gks + ks) * BF_FRAG_BYTES;
       } else if (pc < gks + XKS) {
         const int x = pc - gks;
         ks = x; dst = 16 + x;  // parity of the slot piece = parity of x (x1_ks is even)
-        src = x < x1 ? a.X1 + ((size_t)wb * x1 + x) * BF_FRAG_BYTES : a.X2 + ((size_t)wb * (XKS - x1) + (x - x1)) * BF_FRAG_BYTES;
+        src = x < x1 ? gX1 + ((size_t)wb * x1 + x) * BF_FRAG_BYTES : a.X2 + ((size_t)wb * (XKS - x1) + (x - x1)) * BF_FRAG_BYTES;
       } else {
         ks = pc - gks - XKS; dst = 16 + XKS + ks;
         src = a.Z + ((size_t)wb * 2 + ks) * BF_FRAG_BYTES;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
   // accumulator layout: lane l holds column l & 31 and rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)
   const int NI = NIT * 32, ld = NI + 1;
   const int rows = a.o_tiles * 32 + (HAS_Z ? 32 : 0);
-  float* slab = a.slabs + (size_t)blockIdx.x * rows * ld;
+  float* slab = a.slabs + (size_t)(gi * nwg + wg) * rows * ld;
   const int n = lane & 31, hh = lane >> 5;
   if (worker) {
 #pragma unroll
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void k_dw_bf16_reduce(const DwBfReduceArgs a) 
   }
 }
 
-size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * (256 + 32) * (320 + 1); }
+size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * (256 + 32) * (320 + 1); }  // also covers 6 x 42 slabs of 256 x 257
 
 template <int NIT, bool HAS_Z>
 static hipError_t dwb_launch(const DwBfArgs& a, int wgs, hipStream_t st) {
@@ -226,7 +234,8 @@ static hipError_t dwb_launch(const DwBfArgs& a, int wgs, hipStream_t st) {
 hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned char* X1, int x1_ks, const unsigned char* X2, int x2_ks,
                                const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st) {
   DwBfArgs a;
-  a.G = G; a.X1 = X1; a.X2 = X2 ? X2 : X1; a.Z = Z; a.g_ks = g_ks; a.o_tiles = (g_ks + 1) / 2; a.x1_ks = x1_ks; a.wb_tot = wb_tot; a.slabs = slabs;
+  memset(&a, 0, sizeof(a));
+  a.G[0] = G; a.X1[0] = X1; a.ngemm = 1; a.X2 = X2 ? X2 : X1; a.Z = Z; a.g_ks = g_ks; a.o_tiles = (g_ks + 1) / 2; a.x1_ks = x1_ks; a.wb_tot = wb_tot; a.slabs = slabs;
   const int wgs = wb_tot < DWB_WGS ? wb_tot : DWB_WGS;
   *nslab = wgs;
   const int xks = x1_ks + x2_ks;
@@ -240,6 +249,20 @@ hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned 
     case 2: return dwb_launch<1, false>(a, wgs, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+// n (<= 6) products G_k^T X_k of 256 x 256 outputs in one launch; product k's slabs start at slabs + k * (*nslab) * 256 * 257
+hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned char* const* Xs, int n, int wb_tot, float* slabs, int* nslab,
+                                hipStream_t st) {
+  if (n < 1 || n > 6) return hipErrorInvalidValue;
+  DwBfArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int k = 0; k < n; ++k) { a.G[k] = Gs[k]; a.X1[k] = Xs[k]; }
+  a.X2 = Xs[0]; a.ngemm = n; a.g_ks = 16; a.o_tiles = 8; a.x1_ks = 16; a.wb_tot = wb_tot; a.slabs = slabs;
+  int nwg = DWB_WGS / n;
+  if (nwg > wb_tot) nwg = wb_tot;
+  *nslab = nwg;
+  return dwb_launch<8, false>(a, nwg * n, st);
 }
 
 // slab rows [o_first, o_first + o_count), columns [i_first, i_first + i_count) -> dW[o][col0 + i]; last slab column -> db

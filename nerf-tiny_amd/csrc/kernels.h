@@ -177,6 +177,8 @@ hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, unsigned char* img, 
 size_t dw_bf16_slab_floats();
 hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned char* X1, int x1_ks, const unsigned char* X2, int x2_ks,
                                const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st);
+hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned char* const* Xs, int n, int wb_tot, float* slabs, int* nslab,
+                                hipStream_t st);
 hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count,
                                  float* dW, int ldw, int col0, float* db, hipStream_t st);
 hipError_t launch_dw(const DwProblem& p, hipStream_t st);
