@@ -260,8 +260,9 @@ __device__ __forceinline__ float bf_bias(const Weights24& w, int tile, int i) {
   return i < 3 ? w.p[B_COLOR][i] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_pack_weights_bf16(const Weights24 w, unsigned char* __restrict__ img) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+// first_thread = BF_NFRAG * 64: only the bias block (the 16x16x32 image shares it and brings its own fragments)
+__global__ __launch_bounds__(256) void k_pack_weights_bf16(const Weights24 w, unsigned char* __restrict__ img, int first_thread) {
+  const int gid = first_thread + blockIdx.x * 256 + threadIdx.x;
   if (gid < BF_NFRAG * 64) {
     const int frag = gid >> 6, lane = gid & 63, i = lane & 31, h = lane >> 5;
     u32x4 v;
@@ -282,7 +283,12 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16(const Weights24 w, un
 
 hipError_t launch_pack_weights_bf16(const Weights24& w, unsigned char* img, hipStream_t st) {
   const int threads = BF_NFRAG * 64 + BF_BIAS_BYTES / 4;
-  hipLaunchKernelGGL(k_pack_weights_bf16, dim3((threads + 255) / 256), dim3(256), 0, st, w, img);
+  hipLaunchKernelGGL(k_pack_weights_bf16, dim3((threads + 255) / 256), dim3(256), 0, st, w, img, 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_bias_block_bf16(const Weights24& w, unsigned char* img, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_weights_bf16, dim3((BF_BIAS_BYTES / 4 + 255) / 256), dim3(256), 0, st, w, img, BF_NFRAG * 64);
   return hipGetLastError();
 }
 

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16x(const Weights24 w, u
 }
 
 hipError_t launch_pack_weights_bf16x(const Weights24& w, unsigned char* img, hipStream_t st) {
-  hipError_t e = launch_pack_weights_bf16(w, img, st);  // bias block (and the 32x32x16 fragments, overwritten next)
+  hipError_t e = launch_pack_bias_block_bf16(w, img, st);
   if (e != hipSuccess) return e;
   const int threads = BX_NCHUNK * BF_CHUNK * 64;
   hipLaunchKernelGGL(k_pack_weights_bf16x, dim3((threads + 255) / 256), dim3(256), 0, st, w, img);

@@ -85,6 +85,7 @@ hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_pack_weights_bf16(const Weights24& w, unsigned char* img, hipStream_t st);
+hipError_t launch_pack_bias_block_bf16(const Weights24& w, unsigned char* img, hipStream_t st);
 hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st);  // inference, 16x16x32 MFMA form
 hipError_t launch_pack_weights_bf16x(const Weights24& w, unsigned char* img, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
