@@ -3,16 +3,26 @@
 
 A "step" = one full forward of the hot path (ray generation, 64 coarse + 128 fine samples per ray,
 encode, 8x256 MLP per sample, resample, merge/sort, composite) over one batch of 4096 synthetic rays of
-a 400x400 lego-like view, fp32, inputs already resident in HBM.  `--mode train` times forward + ray_loss +
-backward instead (no optimizer), reported as an extra metric.
+a 400x400 lego-like view, fp32, inputs already resident in HBM.  That is the headline `value`.  The same run
+also times the other three configurations of the path (fp32 train step, bf16-MLP forward and train step: BASELINE.json
+cfg3) for a fraction of a second each and reports them under `extra`, each with its own roofline block.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1: launched under torch.distributed.run,
-one rank per GPU; every rank renders its own 4096-ray batches -- image-space ray batches are independent
-units, so there is no data-path collective: scaling = "weak").  Rank 0 prints ONE JSON line.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  * N > 1 and no RANK in the environment: this process only LAUNCHES -- before torch.cuda or the HIP library is touched it
+    starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    as a child, relays rank 0's single JSON line and exits with the child's code (never exec: MI355X pool rule).
+  * N > 1 under a launcher (RANK / WORLD_SIZE set): one rank per GPU over RCCL.  Every rank renders its own 4096-ray
+    batches -- image-space ray batches are independent units, so the data path has no collective: scaling = "weak".
+    The train legs add the one real exchange of the path, a SUM all-reduce of the 593,924 fp32 gradients (2.27 MiB) in one
+    flat bucket the backward kernels write straight into; its measured time is reported (`allreduce_ms`).
+  * `n_gpus` in the line is `dist.get_world_size()`, not the flag.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,10 +33,59 @@ FLOP_PER_SAMPLE = 1_182_976  # GEMM MACs x 2 of one MLP evaluati
 B, NC, NF = 4096, 64, 128
 FLOP_PER_RAY_FWD = FLOP_PER_SAMPLE * (NC + NF)  # 227,131,392
 FLOP_PER_RAY_TRAIN = 676_282_368
+# backward chain (dX) MACs per sample, SURVEY.md 8(d): coarse pass 557,696, fine pass 588,416 (gamma_p inputs needed for Q9)
+CHAIN_FLOP_COARSE, CHAIN_FLOP_FINE = 2 * 557_696, 2 * 588_416
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md chip table (fp32 matrix, dense)
 PEAK_BF16_MFMA_TFLOPS = 2500.0                   # same table: bf16 matrix, dense (no sparsity)
+PEAK_HBM_GBS = 8000.0
+N_PARAMS = 593_924
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# launcher (N > 1 without a launcher's environment): no torch.cuda, no HIP before the children exist
+# --------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script under torch.distributed.run as a CHILD process, relay rank 0's JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr passes through
+    out, _ = proc.communicate()
+    line = None
+    for ln in out.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            try:
+                json.loads(s)
+                line = s
+            except ValueError:
+                pass
+        elif s:
+            print(s, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0:
+        print(f"bench.py: the {n}-rank job exited with code {proc.returncode}", file=sys.stderr)
+        return proc.returncode
+    if line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return 0
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# synthetic workload
+# --------------------------------------------------------------------------------------------------------------------
 def synth_inputs(seed):
     """cfg2: row, col ~ U{0..399}, one lego-like pose, near/far 2/6.  Pure numpy/torch; the
     same generator as oracle.lego_inputs, restated here so the product path never imports the oracle."""
@@ -119,14 +178,180 @@ def cpu_baseline(seconds_budget=25.0):
     return out
 
 
-def read_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary, if present."""
+def read_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summary (scripts/profile_pmc.sh +
+    scripts/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction).
+    Not measured in this run: the block says so in `traffic_source`."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(p) as f:
-            return json.load(f).get("k_field_fwd", {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(kernel_key, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# one timed leg
+# --------------------------------------------------------------------------------------------------------------------
+class Leg:
+    def __init__(self, name, train, bf16):
+        self.name, self.train, self.bf16 = name, train, bf16
+
+
+def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
+    """W untimed + K timed steps of one configuration, bracketed by barrier + synchronize; returns (elapsed s [max over
+    ranks], per-kernel HIP-event profile of the library, all-reduce ms per step or None)."""
+    import torch
+
+    from nerf_tiny_amd import _abi
+
+    row, col, pb, C_true = inputs
+    model.bf16_mlp = leg.bf16
+    model.grad_bucket = bucket if leg.train else None
+    ar_events = []
+
+    def step(timed):
+        if leg.train:
+            if bucket is None:
+                for p in model.network.parameters():
+                    p.grad = None
+            Cc, Cf = model(row, col, pb, K)
+            loss = model.ray_loss(Cc, Cf, C_true)
+            loss.backward()
+            if bucket is not None and dist is not None:  # data-parallel trainer: ONE flat 2.27 MiB SUM all-reduce over RCCL/xGMI
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                bucket.allreduce_sum()
+                if timed:
+                    e1.record()
+                    ar_events.append((e0, e1))
+        else:
+            with torch.no_grad():
+                model(row, col, pb, K)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(False)
+    fence()
+    _abi.profile_begin(steps * 40 + 40)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = _abi.profile_end()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ar_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)) if ar_events else None
+    model.grad_bucket = None
+    return elapsed, prof, ar_ms
+
+
+def rooflines(leg, prof, b_local, steps):
+    """Roofline blocks of one leg from the library's HIP events (recorded on the stream the kernels run on)."""
+    peak = PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS
+
+    def mfma(kernel, keys, flop_per_launch, traffic_key=None):
+        ms = sum(prof.get(k, (0.0, 0))[0] for k in keys)
+        n = sum(prof.get(k, (0.0, 0))[1] for k in keys)
+        avg = ms / max(n, 1)
+        ach = flop_per_launch / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+        blk = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+               "traffic": read_traffic(traffic_key) if traffic_key else None, "kernel": kernel, "avg_launch_ms": round(avg, 4),
+               "launches": n, "flop_per_launch": flop_per_launch}
+        if traffic_key:
+            blk["traffic_source"] = "profiles/pmc_latest.json (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
+        return blk
+
+    # dominant forward kernel: launched twice per step (coarse pass B*Nc samples, fine pass B*Nf samples); "launch" = the
+    # average launch, so that rocprofv3's per-kernel average is directly comparable
+    fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
+    fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
+               FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, None if (leg.bf16 or leg.train) else "k_field_fwd")
+    if not leg.train:
+        return fwd, None
+    chain = mfma(("k_field_bwd_bf16" if leg.bf16 else "k_field_bwd_reg") + " (dX chain; average of the fine- and coarse-pass launches)",
+                 ("bwd_field_fine", "bwd_field_coarse"), (CHAIN_FLOP_COARSE * b_local * NC + CHAIN_FLOP_FINE * b_local * NF) // 2)
+    # weight-gradient phase: all dW = G^T X products of one step (same MACs as one forward over all samples) + slab reduces + thin heads
+    dw_ms = prof.get("bwd_dw", (0.0, 0))[0] / max(prof.get("bwd_dw", (0.0, 1))[1], 1)
+    if leg.bf16:
+        # HBM-bound by construction (DESIGN.md section 7): bytes of bf16 operands per 32-sample wave block, read once each
+        wb = ((b_local * NC + 255) // 256 + (b_local * NF + 255) // 256) * 8
+        dw_bytes = DW_BF16_KIB_PER_WAVE_BLOCK * 1024 * wb
+        dw = {"bound": "hbm", "achieved": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "frac": round(dw_bytes / (dw_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4), "traffic": None,
+              "kernel": "k_dw_bf16 (the weight-gradient passes + slab reduces of one step)", "avg_launch_ms": round(dw_ms, 4),
+              "launches": prof.get("bwd_dw", (0.0, 0))[1], "bytes_per_launch": dw_bytes}
+    else:
+        flop = FLOP_PER_SAMPLE * b_local * (NC + NF)
+        ach = flop / (dw_ms * 1e-3) / 1e12 if dw_ms > 0 else 0.0
+        dw = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+              "kernel": "k_dw (all weight-gradient products of one step incl. reduces and thin heads = one 'launch')",
+              "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "flop_per_launch": flop}
+    phases = {"forward_with_saves": fwd, "dx_chain": chain, "dw": dw}
+    dominant = max(phases.values(), key=lambda b: b["avg_launch_ms"] * (2 if b is not dw else 1))
+    return dominant, phases
+
+
+DW_BF16_KIB_PER_WAVE_BLOCK = 318  # G and X pieces of bf16_common.h over the 11 products (DESIGN.md section 7)
+
+
+def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong):
+    rays = (B if strong else B * world) * steps
+    value = rays / elapsed
+    flop_ray = FLOP_PER_RAY_TRAIN if leg.train else FLOP_PER_RAY_FWD
+    roof, phases = rooflines(leg, prof, b_local, steps)
+    rep = {"metric": "rays/sec (64 coarse + 128 fine samples), lego 400x400" + (" [train step: fwd+loss+bwd]" if leg.train else "")
+                     + (" [cfg3: bf16 MLP / fp32 composite]" if leg.bf16 else ""),
+           "value": round(value, 1), "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "dtype": "bf16" if leg.bf16 else "f32", "roofline": roof,
+           "whole_path_tflops_per_gpu": round(value / world * flop_ray / 1e12, 2),
+           "whole_path_frac_of_mfma_peak": round(value / world * flop_ray / 1e12 / (PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS), 4),
+           "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in prof.items()}}
+    if phases is not None:
+        rep["roofline_phases"] = phases
+    if leg.train:
+        rep["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
+        rep["allreduce"] = (f"one flat SUM all-reduce of {N_PARAMS} fp32 gradients (2.27 MiB) over RCCL, world {world}" if ar_ms is not None
+                            else "none (single rank without a process group)")
+    return rep
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def dry_main(args):
+    """CPU rehearsal of the N-rank plumbing (tests/test_bench_launch.py): gloo ranks, the same fence / MAX reduction /
+    flat-bucket all-reduce, NO kernels -- the line is marked "dry" and carries no throughput."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist.init_process_group("gloo")
+    if os.environ.get("BENCH_TEST_FAIL_RANK") == str(rank):  # tests/test_bench_launch.py: a dying rank must fail the whole job
+        os._exit(3)
+    flat = torch.full((N_PARAMS,), float(rank + 1))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.fill_(float(rank + 1))
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (gloo, no kernels)", "value": 0.0, "unit": "rays/s", "n_gpus": dist.get_world_size(),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(t) / max(args.steps, 1) * 1e3, 4),
+                          "dry": True, "flag_gpus": args.gpus}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -143,7 +368,20 @@ def main():
                          "batch is split into contiguous slices of 4096/N rays (SURVEY.md 8d cfg3), with the global ray 0's (near, far) "
                          "handed to every rank (quirk Q6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="only the leg named by --mode/--mlp (profiling runs)")
+    ap.add_argument("--dry", action="store_true", help="CPU rehearsal of the launcher + process group over gloo (no kernels; tests only)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # parent of an N-rank job: nothing below this line runs here, in particular no torch.cuda / HIP call
+        return launch_ranks(args.gpus, sys.argv[1:])
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" in os.environ and world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+    if args.dry:
+        return dry_main(args)
 
     import torch
 
@@ -152,7 +390,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     _abi.lib()  # fail loudly if the HIP library is missing
@@ -160,7 +397,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     saved_stdout = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":  # the latter: rehearse the RCCL path with a single rank
+    if world_env > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":  # the latter: rehearse the RCCL path with a single rank
         # RCCL prints a version banner on fd 1; the contract is ONE JSON line on stdout, so native stdout goes to stderr
         # until the result is printed
         sys.stdout.flush()
@@ -169,10 +406,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")  # only the single-rank rehearsal comes without a launcher's environment
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))  # only the single-rank rehearsal comes without a launcher's environment
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+    world = dist.get_world_size() if dist is not None else 1
 
     strong = args.scaling == "strong"
     row, col, pb, K, C_true = synth_inputs(seed=1000 + (0 if strong else rank))
@@ -187,93 +425,47 @@ def main():
         row, col, pb, C_true = row[sl], col[sl], pb[sl], C_true[sl]
         model.batch_ray = b_local
         model.ray0_near_far = ray0
-    bf16 = args.mlp == "bf16"
-    model.bf16_mlp = bf16
-    row, col, pb, C_true = row.to(dev), col.to(dev), pb.float().to(dev), C_true.to(dev)
-    train = args.mode == "train"
-    bucket = P.parallel.GradBucket(model.network.parameters()) if (train and dist is not None) else None
+    inputs = (row.to(dev), col.to(dev), pb.float().to(dev), C_true.to(dev))
+    # the flat gradient buffer of the data-parallel trainer: the backward kernels write into views of it (no pack / unpack)
+    bucket = P.parallel.GradBucket(model.network.parameters())
 
-    def step():
-        if train:
-            for p in model.network.parameters():
-                p.grad = None
-            Cc, Cf = model(row, col, pb, K)
-            loss = model.ray_loss(Cc, Cf, C_true)
-            loss.backward()
-            if bucket is not None:  # data-parallel trainer: one flat 2.27 MiB SUM all-reduce over RCCL/xGMI
-                bucket.allreduce_sum()
-        else:
-            with torch.no_grad():
-                model(row, col, pb, K)
-
-    for _ in range(args.warmup):
-        step()
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    _abi.profile_begin(args.steps * 16 + 16)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = _abi.profile_end()
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    head = Leg("headline", args.mode == "train", args.mlp == "bf16")
+    elapsed, prof, ar_ms = run_leg(head, model, inputs, K, args.steps, args.warmup, dist, dev, bucket)
+    rep = leg_report(head, elapsed, prof, ar_ms, args.steps, args.warmup, world, b_local, strong)
+    extra = {}
+    if not args.no_extra:
+        for name, train, bf16, k, w in (("forward_f32", False, False, 20, 3), ("train_f32", True, False, 8, 2),
+                                        ("forward_bf16", False, True, 50, 5), ("train_bf16", True, True, 20, 3)):
+            if (train, bf16) == (head.train, head.bf16):
+                continue
+            leg = Leg(name, train, bf16)
+            e, p, a = run_leg(leg, model, inputs, K, k, w, dist, dev, bucket)
+            extra[name] = leg_report(leg, e, p, a, k, w, world, b_local, strong)
 
     if rank == 0:
-        rays = (B if strong else B * world) * args.steps
-        value = rays / elapsed
-        # dominant kernel: k_field_fwd, launched twice per step (coarse pass B*Nc samples, fine pass B*Nf samples);
-        # "launch" = the average launch, so that rocprofv3's per-kernel average is directly comparable.
-        ms_sum = prof.get("field_fwd_coarse", (0.0, 0))[0] + prof.get("field_fwd_fine", (0.0, 0))[0]
-        n_launch = prof.get("field_fwd_coarse", (0.0, 0))[1] + prof.get("field_fwd_fine", (0.0, 0))[1]
-        avg_ms = ms_sum / max(n_launch, 1)
-        flop_launch = FLOP_PER_SAMPLE * b_local * (NC + NF) // 2
-        achieved = flop_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        flop_ray = FLOP_PER_RAY_TRAIN if train else FLOP_PER_RAY_FWD
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
         out = {
-            "metric": "rays/sec (64 coarse + 128 fine samples), lego 400x400" + (" [train step: fwd+loss+bwd]" if train else "")
-                      + (" [cfg3: bf16 MLP / fp32 composite]" if bf16 else ""),
-            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "metric": rep["metric"], "value": rep["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": rep["dtype"], "data": "synthetic",
             "config": {"workload": ("cfg3: lego-like 400x400 view, 4096-ray batches, 64 coarse + 128 fine samples, bf16 MLP (fp32 accumulate) / fp32 "
-                                    "everything else, " if bf16 else
+                                    "everything else, " if head.bf16 else
                                     "cfg2: lego-like 400x400 view, 4096-ray batches, 64 coarse + 128 fine samples, fp32, ")
                                    + "random-init 8x256 NeRF MLP (593,924 params)", "rays_per_step_per_gpu": b_local,
-                       "mode": args.mode, "parallelism": f"ray-batch x{world} (independent batches, no collective)" if not train else
+                       "mode": args.mode, "parallelism": f"ray-batch x{world} (independent batches, no collective)" if not head.train else
                        f"ray-batch DP x{world} (one flat SUM all-reduce of 593,924 fp32 gradients per step)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None if bf16 else read_traffic(),
-                         "kernel": (("k_field_fwd_bf16" if train else "k_field_fwd_bf16x") if bf16 else "k_field_fwd_reg") + " (average of the coarse- and fine-pass launches)",
-                         "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
-                         "flop_per_launch": flop_launch},
-            "whole_path_tflops": round(value / world * flop_ray / 1e12, 2),  # per GPU
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+            "roofline": rep["roofline"],
+            "whole_path_tflops": rep["whole_path_tflops_per_gpu"],  # per GPU
+            "kernel_ms_per_step": rep["kernel_ms_per_step"],
         }
-        if bf16 and train and "bwd_dw" in prof:
-            # the bf16 train step is HBM-bound; its dominant phase is the weight-gradient passes: 318 KiB of
-            # bf16 operands per 32-sample wave block (11 passes: G and X pieces of bf16_common.h), read once each
-            wb = ((b_local * NC + 255) // 256 + (b_local * NF + 255) // 256) * 8
-            dw_bytes = 318 * 1024 * wb
-            dw_ms = prof["bwd_dw"][0] / max(prof["bwd_dw"][1], 1)
-            out["roofline"] = {"bound": "hbm", "achieved": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                               "frac": round(dw_bytes / (dw_ms * 1e-3) / 8e12, 4), "traffic": None,
-                               "kernel": "k_dw_bf16 (the 11 weight-gradient passes + slab reduces of one step)",
-                               "avg_launch_ms": round(dw_ms, 4), "launches": prof["bwd_dw"][1], "bytes_per_launch": dw_bytes}
+        for k in ("roofline_phases", "allreduce_ms", "allreduce"):
+            if k in rep:
+                out[k] = rep[k]
+        if extra:
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = round(value / cb["value"], 1)
+            out["gpu_over_cpu"] = round(rep["value"] / cb["value"], 1)
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -281,7 +473,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -120,9 +120,11 @@ int nerf_hip_read_status(const void* ws, size_t ws_bytes, uint32_t* status, void
 
 /*
  * Optional per-kernel timing with HIP events recorded on the caller's stream around every kernel the
- * library launches (used by bench.py for the roofline figure; off by default, not thread-safe).
+ * library launches (used by bench.py for the roofline figure; off by default).  ONE session per process:
  * begin() creates 2*max_launches events; end() waits for them, adds each launch's elapsed ms to
- * ms_sum[kernel id] / count[kernel id] (arrays of n_kernels) and destroys the events.
+ * ms_sum[kernel id] / count[kernel id] (arrays of n_kernels) and destroys the events.  While a session is open,
+ * forward/backward calls from any thread or stream are recorded (slots are handed out under a mutex); begin() and
+ * end() themselves must be called from one thread, and end() only after every call of the session has returned.
  */
 enum {
   NERF_HIP_K_PACK = 0, NERF_HIP_K_RAYS = 1, NERF_HIP_K_FIELD_COARSE = 2, NERF_HIP_K_COARSE = 3,

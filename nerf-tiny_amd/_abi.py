@@ -43,10 +43,6 @@ EXPORTS = tuple(_PROTOS)
 
 _lib = None
 
-#: bumped whenever the library writes network parameters behind torch's back (nerf_hip_adam_step): torch's own
-#: per-tensor ``_version`` counters do not see raw-pointer writes
-weights_epoch = [0]
-
 
 class NerfHipError(RuntimeError):
     pass

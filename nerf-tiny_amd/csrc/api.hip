@@ -8,6 +8,9 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "bf16_common.h"
 #include "kernels.h"
 
@@ -129,8 +132,12 @@ Weights24 as_w24(const float* const* w) {
 }
 
 // ---- optional per-kernel HIP-event timing (bench.py's roofline leg); off by default ----
+// One process-wide session (begin .. end); slots are handed out under a mutex so that callers on several threads /
+// streams may run while a session is open (each launch records its own event pair on its own stream).  begin/end
+// themselves must not race with each other.
 struct Prof {
-  bool on = false;
+  std::atomic<bool> on{false};
+  std::mutex mu;
   int cap = 0, used = 0;
   hipEvent_t* ev = nullptr;  // 2 per launch
   int* kid = nullptr;
@@ -138,16 +145,23 @@ struct Prof {
 
 struct ProfScope {
   hipStream_t st;
-  int slot = -1;
+  hipEvent_t stop = nullptr;
   ProfScope(int kernel_id, hipStream_t s) : st(s) {
-    if (g_prof.on && g_prof.used < g_prof.cap) {
-      slot = g_prof.used++;
-      g_prof.kid[slot] = kernel_id;
-      (void)hipEventRecord(g_prof.ev[2 * slot], st);
+    if (!g_prof.on.load(std::memory_order_acquire)) return;
+    hipEvent_t start = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_prof.mu);
+      if (g_prof.on.load(std::memory_order_relaxed) && g_prof.used < g_prof.cap) {
+        const int slot = g_prof.used++;
+        g_prof.kid[slot] = kernel_id;
+        start = g_prof.ev[2 * slot];
+        stop = g_prof.ev[2 * slot + 1];
+      }
     }
+    if (start) (void)hipEventRecord(start, st);
   }
   ~ProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+    if (stop) (void)hipEventRecord(stop, st);
   }
 };
 
@@ -277,13 +291,16 @@ int nerf_hip_profile_begin(int max_launches) {
   for (int i = 0; i < 2 * max_launches; ++i) HIP_TRY(hipEventCreate(&g_prof.ev[i]));
   g_prof.cap = max_launches;
   g_prof.used = 0;
-  g_prof.on = true;
+  g_prof.on.store(true, std::memory_order_release);
   return NERF_HIP_OK;
 }
 
 int nerf_hip_profile_end(double* ms_sum, int* count, int n_kernels) {
   if (!g_prof.ev) return fail(NERF_HIP_ERR_ARG, "profile not active");
-  g_prof.on = false;
+  {
+    std::lock_guard<std::mutex> lk(g_prof.mu);  // no slot is handed out after this point
+    g_prof.on.store(false, std::memory_order_release);
+  }
   for (int k = 0; k < n_kernels; ++k) { if (ms_sum) ms_sum[k] = 0.0; if (count) count[k] = 0; }
   int rc = NERF_HIP_OK;
   for (int i = 0; i < g_prof.used; ++i) {

@@ -219,13 +219,9 @@ size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * (256 + 32) * (320 + 1); 
 
 template <int NIT, bool HAS_Z>
 static hipError_t dwb_launch(const DwBfArgs& a, int wgs, hipStream_t st) {
-  static bool attr_done = false;
+  static std::atomic<unsigned long long> opted{0};
   using Geo = DwbGeom<NIT, HAS_Z>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw_bf16<NIT, HAS_Z>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_dw_bf16<NIT, HAS_Z>)}, Geo::LDS_BYTES)) return e;
   hipLaunchKernelGGL((k_dw_bf16<NIT, HAS_Z>), dim3(wgs), dim3(BF_WG), Geo::LDS_BYTES, st, a);
   return hipGetLastError();
 }

@@ -485,12 +485,8 @@ __global__ __launch_bounds__(128) void k_dir_gamma_dw(const SmallGradArgs a) {
 hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st) {
   const int tiles = (a.M + TM - 1) / TM;
   const size_t lds = FIELD_LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> opted{0};
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(k_field_bwd<false>), reinterpret_cast<const void*>(k_field_bwd<true>)}, (int)lds)) return e;
   if (fine)
     hipLaunchKernelGGL(k_field_bwd<true>, dim3(tiles), dim3(256), lds, st, a);
   else

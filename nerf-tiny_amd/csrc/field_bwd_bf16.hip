@@ -248,14 +248,8 @@ hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, unsigned char* img, 
 }
 
 hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_bf16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_bf16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> opted{0};
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_bwd_bf16<false>), reinterpret_cast<const void*>(&k_field_bwd_bf16<true>)}, BB_LDS_BYTES)) return e;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
   if (fine)
     hipLaunchKernelGGL((k_field_bwd_bf16<true>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a);

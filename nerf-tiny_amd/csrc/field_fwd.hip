@@ -365,12 +365,8 @@ hipError_t launch_field_fwd(const FieldArgs& a_in, bool save, hipStream_t st) {
   const FieldArgs& a = a_in;
   const int tiles = (a.M + TM - 1) / TM;
   const size_t lds = FIELD_LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> opted{0};
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(k_field_fwd<false>), reinterpret_cast<const void*>(k_field_fwd<true>)}, (int)lds)) return e;
   if (save)
     hipLaunchKernelGGL(k_field_fwd<true>, dim3(tiles), dim3(256), lds, st, a);
   else

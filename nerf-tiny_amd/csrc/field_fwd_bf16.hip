@@ -293,14 +293,8 @@ hipError_t launch_pack_bias_block_bf16(const Weights24& w, unsigned char* img, h
 }
 
 hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st) {
-  static bool attr_done = false;  // >64 KiB of dynamic LDS needs an opt-in, once per process and device function
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_bf16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_bf16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> opted{0};  // >64 KiB of dynamic LDS needs an opt-in, once per device and kernel
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16<false>), reinterpret_cast<const void*>(&k_field_fwd_bf16<true>)}, BF_LDS_BYTES)) return e;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
   if (save)
     hipLaunchKernelGGL((k_field_fwd_bf16<true>), dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);

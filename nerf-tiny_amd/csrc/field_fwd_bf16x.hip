@@ -282,12 +282,8 @@ hipError_t launch_pack_weights_bf16x(const Weights24& w, unsigned char* img, hip
 }
 
 hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_bf16x), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> opted{0};
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16x)}, BF_LDS_BYTES)) return e;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
   hipLaunchKernelGGL(k_field_fwd_bf16x, dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);
   return hipGetLastError();

@@ -2,7 +2,26 @@
 #pragma once
 #include "common.h"
 
+#include <atomic>
+#include <initializer_list>
+
 namespace nerf {
+
+// More than 64 KiB of dynamic LDS needs an opt-in per kernel -- and per DEVICE: the attribute belongs to the function's
+// code object on the current device, so a process that moves to a second GPU must set it again.  `mask` = one bit per
+// device ordinal already done (a static at the call site); ordinals >= 64 simply set it on every launch.
+inline hipError_t ensure_dynamic_lds(std::atomic<unsigned long long>& mask, std::initializer_list<const void*> kernels, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 64 && ((mask.load(std::memory_order_relaxed) >> dev) & 1ull)) return hipSuccess;
+  for (const void* k : kernels) {
+    e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+  }
+  if (dev < 64) mask.fetch_or(1ull << dev, std::memory_order_relaxed);
+  return hipSuccess;
+}
 
 constexpr int LDA = 260;  // floats per LDS activation row of the field kernels
 constexpr int FIELD_LDS_FLOATS = TM * LDA + 4 * TM * 3;

@@ -342,10 +342,12 @@ size_t merge_lds_bytes(int P) { return (size_t)5 * P * (sizeof(float) + sizeof(u
 hipError_t launch_merge(const MergeArgs& a, hipStream_t st) {
   const size_t lds = merge_lds_bytes(a.P);
   if (a.perm) {
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024)
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     hipLaunchKernelGGL(k_merge<true>, dim3(a.B), dim3(64), lds, st, a);
   } else {
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024)
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     hipLaunchKernelGGL(k_merge<false>, dim3(a.B), dim3(64), lds, st, a);
   }
   return hipGetLastError();

@@ -252,7 +252,8 @@ hipError_t launch_merge_bwd(const MergeBwdArgs& a, hipStream_t st) {
 }
 hipError_t launch_coarse_bwd(const CoarseBwdArgs& a, hipStream_t st) {
   const size_t lds = (size_t)4 * 5 * a.Nc * sizeof(float) + (size_t)4 * ((a.Nf + 1) & ~1) * sizeof(uint16_t);
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024)
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
   hipLaunchKernelGGL(k_coarse_bwd, dim3((a.B + 3) / 4), dim3(256), lds, st, a);
   return hipGetLastError();
 }

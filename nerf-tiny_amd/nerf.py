@@ -10,6 +10,7 @@ There is NO fallback: calling a model that does not live on a ROCm device raises
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import torch
@@ -78,12 +79,11 @@ class _RenderFn(torch.autograd.Function):
         flags = ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
                  | (_abi.BF16_MLP if getattr(model, "bf16_mlp", False) else 0))
         ws = model._workspace(B, flags)
-        # rendering loops: the packed weight image of the previous call on this workspace is still valid if no parameter has
-        # been written since (torch bumps a tensor's _version on every in-place update; FusedAdam, which writes through the
-        # C ABI, bumps _abi.weights_epoch)
-        stamp = (ws.data_ptr(), flags, _abi.weights_epoch[0]) + tuple((p.data_ptr(), p._version) for p in params)
-        call_flags = flags | (_abi.WEIGHTS_UNCHANGED if (not need_grad and getattr(model, "_packed_stamp", None) == stamp) else 0)
-        model._packed_stamp = stamp
+        # rendering loops (`with model.frozen_weights():`): the packed weight image a previous call of the SAME frozen section
+        # left in this workspace is reused.  Outside such a section the image is rebuilt on every call (12 us): a version
+        # stamp cannot see writes through `.data`, dist.broadcast or raw pointers.
+        reuse = model._frozen and not need_grad and (ws.data_ptr(), flags) in model._packed
+        call_flags = flags | (_abi.WEIGHTS_UNCHANGED if reuse else 0)
         dev = row.device
         C_c = torch.empty(B, 3, dtype=torch.float32, device=dev)
         C_f = torch.empty(B, 3, dtype=torch.float32, device=dev)
@@ -92,9 +92,13 @@ class _RenderFn(torch.autograd.Function):
         _abi.check(_abi.lib().nerf_hip_forward(wptr, row.data_ptr(), col.data_ptr(), pb.data_ptr(), K9,
                                                ray0, B, Nc, Nf, LAST_DELTA, C_c.data_ptr(), C_f.data_ptr(),
                                                ws.data_ptr(), ws.numel(), call_flags, stream))
+        if model._frozen and not need_grad:
+            model._packed.add((ws.data_ptr(), flags))
+        model._last_ws = ws
         if need_grad:
-            model._ws_generation += 1
-            ctx.generation = model._ws_generation
+            gen = model._ws_generation.get(flags, 0) + 1
+            model._ws_generation[flags] = gen
+            ctx.generation = gen
             ctx.model, ctx.ws, ctx.flags, ctx.B = model, ws, flags, B
             ctx.params, ctx.ray0 = params, ray0
         return C_c, C_f
@@ -102,16 +106,29 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dC_c, dC_f):
         model = ctx.model
-        if ctx.generation != model._ws_generation:
-            raise RuntimeError("the workspace of this forward was reused by a later forward; call backward first")
+        if ctx.generation != model._ws_generation.get(ctx.flags):
+            raise RuntimeError("the workspace of this forward was reused by a later training forward; call backward first")
         params = ctx.params
-        grads = [torch.empty_like(p) for p in params]
+        bucket = model.grad_bucket
+        if bucket is not None:
+            # data-parallel trainer: the kernels write straight into views of the flat all-reduce buffer (parallel.GradBucket)
+            if len(bucket.params) != len(params) or any(a is not b for a, b in zip(bucket.params, params)):
+                raise RuntimeError("model.grad_bucket was built for other parameters")
+            grads = bucket.views
+        else:
+            grads = [torch.empty_like(p) for p in params]
         dC_c = dC_c.contiguous().float()
         dC_f = dC_f.contiguous().float()
         stream = torch.cuda.current_stream(dC_c.device).cuda_stream
         _abi.check(_abi.lib().nerf_hip_backward(_abi.ptr_array(params), dC_c.data_ptr(), dC_f.data_ptr(), ctx.ray0, ctx.B,
                                                 model.num_coarse, model.num_fine, LAST_DELTA, _abi.ptr_array(grads),
                                                 ctx.ws.data_ptr(), ctx.ws.numel(), ctx.flags, stream))
+        if bucket is not None:
+            # p.grad IS the bucket view (overwritten every step, like the C ABI's dweights24): nothing for autograd to accumulate
+            for p, v in zip(params, grads):
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
+            return (None,) * (7 + len(params))
         return (None, None, None, None, None, None, None, *grads)
 
 
@@ -133,27 +150,68 @@ class NeRFModel(nn.Module):
         self.force_tile_kernel = False
         #: BASELINE.json cfg3: run the MLP on bf16 MFMA (fp32 accumulation, fp32 everything else); ~1e-2 of the fp32 result
         self.bf16_mlp = False
-        self._ws = {}
-        self._ws_generation = 0
-        self._packed_stamp = None
+        #: parallel.GradBucket or None.  When set, backward writes the 24 gradients straight into the bucket's flat buffer and
+        #: makes p.grad its views (overwrite semantics: one backward per step), so the all-reduce needs no pack / unpack
+        self.grad_bucket = None
+        self._ws = {}            # flags -> (key, workspace): one slot per flag set (training / inference / bf16 ...)
+        self._ws_generation = {}  # flags -> count of training forwards on that slot
+        self._last_ws = None
+        self._frozen = False
+        self._packed = set()
 
     # ----- plumbing -------------------------------------------------------------------------
     def _workspace(self, B, flags):
+        """One workspace per flag set, so that a validate-while-training loop (17 GB training workspace at cfg2 + a small
+        inference one) does not reallocate on every switch; a slot is replaced when its sizes or device change."""
         dev = self.network.point_info.weight.device
         key = (B, self.num_coarse, self.num_fine, flags, dev)
-        ws = self._ws.get(key)
-        if ws is None:
+        slot = self._ws.get(flags)
+        if slot is None or slot[0] != key:
+            self._ws.pop(flags, None)
+            slot = None
             n = _abi.ws_bytes(B, self.num_coarse, self.num_fine, flags)
             ws = torch.empty(n, dtype=torch.uint8, device=dev)
             assert ws.data_ptr() % 256 == 0
-            self._ws = {key: ws}  # keep one workspace alive
-        return ws
+            self._ws[flags] = slot = (key, ws)
+            self._packed = {k for k in self._packed if k[1] != flags}
+        return slot[1]
+
+    @property
+    def last_workspace(self):
+        """The workspace the most recent forward ran on (introspection: _abi.ws_view, status word)."""
+        return self._last_ws
+
+    @contextlib.contextmanager
+    def frozen_weights(self):
+        """Rendering loops: inside this section the caller guarantees that no parameter is written, so the packed weight
+        image is built once per workspace and reused (NERF_HIP_WEIGHTS_UNCHANGED) instead of rebuilt on every call.
+        Opt-in because no stamp can see every write (``p.data.add_()``, ``dist.broadcast(p.data)``, raw pointers)."""
+        prev = self._frozen
+        self._frozen = True
+        if not prev:
+            self._packed = set()
+        try:
+            yield self
+        finally:
+            self._frozen = prev
+            if not prev:
+                self._packed = set()
 
     def __getstate__(self):  # torch.save(model) (nerf.py:491) must not pickle the workspace
         d = dict(self.__dict__)
         d["_ws"] = {}
-        d["_packed_stamp"] = None
+        d["_ws_generation"] = {}
+        d["_last_ws"] = None
+        d["_packed"] = set()
+        d["_frozen"] = False
+        d["grad_bucket"] = None
         return d
+
+    def __setstate__(self, d):  # checkpoints written by an earlier build lack the newer plumbing attributes
+        super().__setstate__(d)
+        self.__dict__.setdefault("grad_bucket", None)
+        self.__dict__["_ws"], self.__dict__["_ws_generation"] = {}, {}
+        self.__dict__["_last_ws"], self.__dict__["_packed"], self.__dict__["_frozen"] = None, set(), False
 
     def _params(self):
         ps = list(self.network.parameters())
@@ -185,7 +243,7 @@ class NeRFModel(nn.Module):
         C_c, C_f = _RenderFn.apply(self, need_grad, row_d, col_d, pb, K9, ray0, *ps)
         if self.check_resample:
             st = C.c_uint32(0)
-            ws = next(iter(self._ws.values()))
+            ws = self._last_ws
             _abi.check(_abi.lib().nerf_hip_read_status(ws.data_ptr(), ws.numel(), C.byref(st),
                                                        torch.cuda.current_stream(dev).cuda_stream))
             if st.value & _abi.STATUS_RESAMPLE_INDEX:

@@ -30,26 +30,33 @@ def global_ray0(poses_bound: torch.Tensor) -> tuple[float, float]:
 
 
 class GradBucket:
-    """One flat fp32 buffer aliasing the gradients of `params` (in parameters() order) so that a single
-    all-reduce moves all 2.27 MiB (latency-bound on xGMI: one collective instead of 24)."""
+    """One flat fp32 buffer holding the gradients of `params` (in parameters() order) so that a single all-reduce moves
+    all 2.27 MiB (latency-bound on xGMI: one collective instead of 24).  With ``model.grad_bucket = bucket`` the backward
+    kernels write straight into `views` and ``p.grad`` ARE those views, so `allreduce_sum` is the collective alone;
+    gradients that live elsewhere (plain autograd, the gloo tests) are copied in and out."""
+
+    ALIGN = 64  # floats: every view starts on a 256-byte boundary (the C ABI wants dweights24 16-byte aligned; sigma bias has 1 element)
 
     def __init__(self, params):
         self.params = list(params)
-        n = sum(p.numel() for p in self.params)
         p0 = self.params[0]
-        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
-        self.views = []
-        o = 0
+        offs, o = [], 0
         for p in self.params:
-            self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+            offs.append(o)
+            o += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.numel = sum(p.numel() for p in self.params)  # 593,924 real gradients; the padding stays zero
+        self.flat = torch.zeros(o, dtype=p0.dtype, device=p0.device)
+        self.views = [self.flat[a:a + p.numel()].view_as(p) for a, p in zip(offs, self.params)]
+
+    def _foreign(self):
+        return [(v, p) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
 
     def pack(self):
-        for v, p in zip(self.views, self.params):
+        for v, p in self._foreign():
             v.copy_(p.grad)
 
     def unpack(self):
-        for v, p in zip(self.views, self.params):
+        for v, p in self._foreign():
             p.grad.copy_(v)
 
     def allreduce_sum(self, group=None):
@@ -61,44 +68,79 @@ class GradBucket:
 def train_step_sharded(model, bucket: GradBucket, row, col, poses_bound, K_inv, C_true, rank: int, world: int, group=None):
     """One data-parallel train step on this rank's slice of a GLOBAL batch (every rank passes the same global tensors).
     `model.batch_ray` must equal the slice size.  Returns this rank's (C_coarse, C_fine, local loss); after the call
-    every rank holds the full-batch gradient in p.grad (sum over ranks)."""
+    every rank holds the full-batch gradient in p.grad (sum over ranks; p.grad are views of `bucket.flat`).  The collective
+    sits where the reference has ``loss.backward(); optimizer.step()`` (nerf.py:473-474)."""
     lo, hi = shard_bounds(row.shape[0], rank, world)
+    prev_ray0, prev_bucket = model.ray0_near_far, model.grad_bucket
     model.ray0_near_far = global_ray0(poses_bound)
-    for p in bucket.params:
-        p.grad = None
-    C_c, C_f = model(row[lo:hi], col[lo:hi], poses_bound[lo:hi], K_inv)
-    loss = model.ray_loss(C_c, C_f, C_true[lo:hi])
-    loss.backward()
-    if world > 1:
+    model.grad_bucket = bucket
+    try:
+        C_c, C_f = model(row[lo:hi], col[lo:hi], poses_bound[lo:hi], K_inv)
+        loss = model.ray_loss(C_c, C_f, C_true[lo:hi])
+        loss.backward()
+    finally:
+        model.ray0_near_far, model.grad_bucket = prev_ray0, prev_bucket
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         bucket.allreduce_sum(group)
     return C_c, C_f, loss
 
 
-def render_rows_sharded(model, row, col, poses_bound, K_inv, rank: int, world: int, out: torch.Tensor | None = None):
-    """Inference over a long list of rays (e.g. one frame): this rank renders the contiguous slice
-    [lo, hi) in batches of model.batch_ray (the tail batch is padded by repeating the last ray and cropped -- the
-    reference would silently drop it, nerf.py:442).  No collective.  Returns (lo, hi, C_fine[hi-lo, 3])."""
-    lo, hi = shard_bounds(row.shape[0], rank, world)
-    Bm = model.batch_ray
-    model.ray0_near_far = global_ray0(poses_bound)
+def batch_shard_bounds(n: int, batch: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous ray range [lo, hi) of `rank` when n rays are dealt out in whole batches of `batch` rays (the last batch may
+    be short): shards start on the batch grid of the reference's display loop (nerf.py:503-520, one DataLoader batch =
+    rays [g*batch, (g+1)*batch))."""
+    nb = (n + batch - 1) // batch
+    lo_b, hi_b = shard_bounds(nb, rank, world)
+    return min(lo_b * batch, n), min(hi_b * batch, n)
+
+
+def render_rows_sharded(model, row, col, poses_bound, K_inv, rank: int, world: int, out: torch.Tensor | None = None,
+                        align_to_batches: bool = True):
+    """Inference over a long list of rays (e.g. one frame): this rank renders a contiguous range [lo, hi) in batches of
+    model.batch_ray.  No collective.  Returns (lo, hi, C_fine[hi-lo, 3]).
+
+    The reference renders the list in DataLoader batches [g*Bm, (g+1)*Bm) and its resampler takes the coarse spacing from
+    ray 0 OF EACH BATCH (nerf.py:233, quirk Q6).  To return the same pixels for any sharding, every kernel call here covers
+    rays of ONE reference batch and is handed that batch's ray 0 (near, far); with `align_to_batches` (default) shards start
+    on the batch grid, so only the global tail batch is short.  A short piece is padded by repeating its last ray and cropped
+    (the reference silently drops the tail batch, nerf.py:442; here it is rendered, with its own ray 0)."""
+    n, Bm = row.shape[0], model.batch_ray
+    lo, hi = batch_shard_bounds(n, Bm, rank, world) if align_to_batches else shard_bounds(n, rank, world)
     res = []
-    with torch.no_grad():
-        for s in range(lo, hi, Bm):
-            e = min(s + Bm, hi)
-            idx = torch.arange(s, s + Bm).clamp_max(e - 1)
-            _, C_f = model(row[idx], col[idx], poses_bound[idx], K_inv)
-            res.append(C_f[: e - s].clone())
+    prev_ray0 = model.ray0_near_far
+    try:
+        if hi > lo:
+            g0, g1 = lo // Bm, (hi - 1) // Bm
+            starts = torch.arange(g0, g1 + 1) * Bm
+            nf0 = poses_bound[starts.to(poses_bound.device)][:, 15:17].to(torch.float32).cpu()  # ONE host copy for the whole range
+        with torch.no_grad(), model.frozen_weights():
+            s = lo
+            while s < hi:
+                g = s // Bm
+                e = min((g + 1) * Bm, hi)
+                model.ray0_near_far = (float(nf0[g - g0, 0]), float(nf0[g - g0, 1]))
+                if e - s == Bm:
+                    r, c, pb = row[s:e], col[s:e], poses_bound[s:e]
+                else:
+                    idx = torch.arange(s, s + Bm, device=row.device).clamp_max(e - 1)
+                    r, c, pb = row[idx], col[idx], poses_bound[idx.to(poses_bound.device)]
+                _, C_f = model(r, c, pb, K_inv)
+                res.append(C_f[: e - s].clone())
+                s = e
+    finally:
+        model.ray0_near_far = prev_ray0
     C = torch.cat(res) if res else torch.empty(0, 3)
-    if out is not None:
+    if out is not None and hi > lo:
         out[lo:hi] = C
     return lo, hi, C
 
 
-def gather_rows(C_local: torch.Tensor, n_total: int, rank: int, world: int, group=None) -> torch.Tensor:
-    """Assemble the full [n_total, 3] picture on every rank (outside the timed data path)."""
+def gather_rows(C_local: torch.Tensor, n_total: int, rank: int, world: int, group=None, bounds=None) -> torch.Tensor:
+    """Assemble the full [n_total, 3] picture on every rank (outside the timed data path).  `bounds`: list of every rank's
+    (lo, hi) when the shards are not `shard_bounds` (e.g. `batch_shard_bounds`)."""
     if world == 1:
         return C_local
-    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
+    sizes = bounds if bounds is not None else [shard_bounds(n_total, r, world) for r in range(world)]
     mx = max(h - l for l, h in sizes)
     pad = torch.zeros(mx, 3, dtype=C_local.dtype, device=C_local.device)
     pad[: C_local.shape[0]] = C_local

@@ -64,7 +64,6 @@ class FusedAdam(torch.optim.Optimizer):
         _abi.check(_abi.lib().nerf_hip_adam_step(_abi.ptr_array(ps), _abi.ptr_array([p.grad.contiguous() for p in ps]),
                                                  self._m.data_ptr(), self._v.data_ptr(), self._step, float(g["lr"]), float(b1),
                                                  float(b2), float(g["eps"]), torch.cuda.current_stream(dev).cuda_stream))
-        _abi.weights_epoch[0] += 1  # parameters changed without torch noticing: cached packed weight images are stale
         for p in ps:
             self.state[p]["step"] = torch.tensor(float(self._step))
         return None
@@ -184,7 +183,7 @@ class NeRFRunner:
         rays = self.disp_rays
         result = torch.full((rays.pic_num, self.height, self.width, 3), 1.0, device=self.device)
         self.model.eval()
-        with torch.no_grad():
+        with torch.no_grad(), self.model.frozen_weights():  # nothing writes the parameters inside this loop: pack the weights once
             for row, col, pix_val, poses_bound, pic in rays.epoch(self.batch_ray, shuffle=False):  # tail < batch stays white
                 _, C_fine = self.model(row, col, poses_bound, self.K_inv)
                 result[pic, row, col] = C_fine

@@ -14,7 +14,7 @@ m.force_tile_kernel = os.environ.get("NERF_STAMP_TILE") == "1"
 row, col, pb = row.to(dev), col.to(dev), pb.float().to(dev)
 with torch.no_grad():
     m(row, col, pb, K)
-    ws = next(iter(m._ws.values()))
+    ws = m.last_workspace
     st = ws[:256].view(torch.int64)
     st[8:16] = 0
     m(row, col, pb, K)

@@ -49,7 +49,7 @@ def _relu_mask_image(hidden, tiles):
 def _views(pkg, m, B, Nc, Nf):
     from nerf_tiny_amd import _abi
 
-    ws = next(iter(m._ws.values()))
+    ws = m.last_workspace
     return lambda name, shape, dt=None: _abi.ws_view(ws, B, Nc, Nf, _abi.SAVE_FOR_BACKWARD, name, shape, dt)
 
 

@@ -119,7 +119,7 @@ def test_bf16_saved_activations_and_gradients_coarse_only(oracle, pkg, dev, name
     m = _bf16_model(pkg, params, Nc, Nf, B, dev)
     Cc, Cf = m(row.to(dev), col.to(dev), pb.to(dev), K)
     flags = _abi.SAVE_FOR_BACKWARD | _abi.BF16_MLP
-    ws = next(iter(m._ws.values()))
+    ws = m.last_workspace
     wb_c, wb_tot = _wave_blocks(B, Nc), _wave_blocks(B, Nc) + _wave_blocks(B, Nf)
     bsave = _abi.ws_view(ws, B, Nc, Nf, flags, "bsave", (wb_tot * sum(BS_KS) * 1024,), torch.uint8)
 

@@ -231,32 +231,70 @@ def test_render_rows_sharded_frame_with_tail(oracle, pkg, dev):
     assert max_rel(out, of) < TOL
 
 
-def test_packed_weights_are_reused_only_while_unchanged(oracle, pkg, dev):
-    """rendering loops skip the weight re-packing (NERF_HIP_WEIGHTS_UNCHANGED); any parameter update -- through torch or
-    through the fused Adam kernel -- must invalidate the cached image"""
+def test_packed_weights_are_reused_only_inside_a_frozen_section(oracle, pkg, dev):
+    """rendering loops skip the weight re-packing (NERF_HIP_WEIGHTS_UNCHANGED) only inside `with model.frozen_weights():`;
+    outside it every call repacks, so ANY parameter write is seen -- also the ones no version stamp can see (`p.data.add_()`,
+    raw-pointer writes of the fused Adam kernel)"""
     B, Nc, Nf = 64, 16, 32
     row, col, pb, K, Ct = oracle.lego_inputs(B, seed=2)
     w = oracle.make_weights(5)
     m = pkg.NeRFModel(Nc, Nf, B)
     m.load_state_dict(w)
     m = m.to(dev)
+
+    def check_against_oracle(out):
+        oc, of = oracle.render({k: v.detach().cpu() for k, v in m.state_dict().items()}, row, col, pb, K, Nc, Nf)
+        assert max_rel(out[0], oc) < TOL and max_rel(out[1], of) < TOL
+
     with torch.no_grad():
         a = m(row, col, pb, K)
-        b = m(row, col, pb, K)  # second call: cached image
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-        m.network.point_info.bias.add_(0.05)  # torch-visible update
+        with m.frozen_weights():
+            b = m(row, col, pb, K)  # packs
+            b2 = m(row, col, pb, K)  # reuses the packed image
+            assert (m.last_workspace.data_ptr(), 0) in m._packed
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b2[1]) and not m._packed
+        m.network.point_info.bias.data.add_(0.05)  # invisible to torch's version counter
         c = m(row, col, pb, K)
         assert not torch.equal(a[0], c[0])
-        w2 = {k: v.clone() for k, v in m.state_dict().items()}
-        oc, of = oracle.render({k: v.cpu() for k, v in w2.items()}, row, col, pb, K, Nc, Nf)
-        assert max_rel(c[0], oc) < TOL and max_rel(c[1], of) < TOL
-    # update through the C ABI (fused Adam): invisible to torch's version counters
+        check_against_oracle(c)
+        with m.frozen_weights():  # a new section never trusts an older image
+            c2 = m(row, col, pb, K)
+        assert torch.equal(c[0], c2[0]) and torch.equal(c[1], c2[1])
+    # update through the C ABI (fused Adam)
     opt = pkg.train.FusedAdam(list(m.network.parameters()), lr=1e-2)
     Cc, Cf = m(row, col, pb, K)
     m.ray_loss(Cc, Cf, Ct.to(dev)).backward()
     opt.step()
     with torch.no_grad():
         d = m(row, col, pb, K)
-        od = oracle.render({k: v.detach().cpu() for k, v in m.state_dict().items()}, row, col, pb, K, Nc, Nf)
     assert not torch.equal(d[0], c[0])
-    assert max_rel(d[0], od[0]) < TOL and max_rel(d[1], od[1]) < TOL
+    check_against_oracle(d)
+
+
+def test_training_and_inference_workspaces_coexist(oracle, pkg, dev):
+    """one workspace slot per flag set: an inference call between a training forward and its backward neither reallocates
+    nor disturbs the saved activations (validate-while-training loops)"""
+    B, Nc, Nf = 64, 16, 32
+    row, col, pb, K, Ct = oracle.lego_inputs(B, seed=2)
+    m = pkg.NeRFModel(Nc, Nf, B)
+    m.load_state_dict(oracle.make_weights(5))
+    m = m.to(dev)
+    Cc, Cf = m(row, col, pb, K)
+    m.ray_loss(Cc, Cf, Ct.to(dev)).backward()
+    g0 = [p.grad.clone() for p in m.network.parameters()]
+    ws_train = m.last_workspace
+    for p in m.network.parameters():
+        p.grad = None
+    Cc, Cf = m(row, col, pb, K)
+    assert m.last_workspace.data_ptr() == ws_train.data_ptr()
+    with torch.no_grad():
+        m(row, col, pb, K)  # inference in between: its own slot
+    assert m.last_workspace.data_ptr() != ws_train.data_ptr() and len(m._ws) == 2
+    m.ray_loss(Cc, Cf, Ct.to(dev)).backward()
+    for p, g in zip(m.network.parameters(), g0):
+        assert torch.equal(p.grad, g)
+    # a second TRAINING forward on the same slot invalidates the first one's backward
+    C1 = m(row, col, pb, K)
+    m(row, col, pb, K)
+    with pytest.raises(RuntimeError):
+        m.ray_loss(C1[0], C1[1], Ct.to(dev)).backward()

@@ -104,3 +104,88 @@ def test_parity_on_trained_weights(oracle, pkg, dev):
     ec, ef = max_rel(Cc, oc), max_rel(Cf, of)
     print(f"trained weights: max-rel C_coarse {ec:.2e} C_fine {ef:.2e}")
     assert ec < 1e-4 and ef < 1e-4
+
+
+def test_gather_rays_matches_reference_loader_tuples(pkg, dev, tmp_path):
+    """k_gather_rays against the tuples the REFERENCE's NeRFDataset.__getitem__ returned (tests/golden/data_golden.npz,
+    written by make_data_golden.py from /root/reference/loader.py): row, column, picture exact; pixel bit-exact; pose row =
+    the float32 cast the model applies at nerf.py:338."""
+    import sys
+
+    from conftest import GOLDEN, load_golden
+
+    sys.path.insert(0, GOLDEN)
+    from data_trees import write_blender_tree, write_llff_tree
+
+    g = load_golden("data_golden")
+    broot, lroot = str(tmp_path) + "/blender/", str(tmp_path) + "/llff/"
+    write_blender_tree(broot, "train", g["b_rgba"], g["b_mats"], float(g["b_angle"]))
+    write_llff_tree(lroot, g["l_rgb"], g["l_poses_bounds"])
+    for k, root, typ in (("b", broot, "sync"), ("l", lroot, "llff")):
+        ds = pkg.data.NeRFDataset(root_dir=root, low_res=1, transform=None, type=typ, mode="train")
+        rays = pkg.data.DeviceRays(ds, dev, seed=0)
+        row, col, pix, pb, pic = rays.gather(torch.from_numpy(g[k + "_idx"]).to(dev))
+        assert row.cpu().tolist() == g[k + "_item_row"].tolist() and col.cpu().tolist() == g[k + "_item_col"].tolist()
+        assert pic.cpu().tolist() == g[k + "_item_pic"].tolist()
+        assert pix.cpu().numpy().tobytes() == g[k + "_item_pix"].tobytes()
+        assert pb.cpu().numpy().tobytes() == torch.from_numpy(g[k + "_item_pose"]).to(torch.float).numpy().tobytes()
+
+
+def test_reference_main_call_sequence(oracle, pkg, dev, tmp_path, monkeypatch):
+    """Replays /root/reference/main.py:10-56 against this package: `from nerf import NeRFRunner`, the 17 ini keys parsed the
+    way main.py parses them (LR_MILESTONE becomes a list of characters, CONTINUE goes through eval), NeRFRunner(**17 kwargs),
+    `trainer()` WITHOUT an argument, `display()` -- on a Blender tree on disk (train/val/test) -- and compares one displayed
+    frame with the oracle rendering the same rays with the trained weights in the reference's display batches."""
+    import sys
+    from configparser import ConfigParser
+
+    from conftest import GOLDEN, max_rel
+
+    sys.path.insert(0, GOLDEN)
+    from data_trees import write_blender_tree
+
+    from nerf import NeRFRunner  # main.py:4
+
+    n_pic, H, W = 3, 32, 32
+    scene = pkg.data.analytic_sphere_scene(n_pic=n_pic, H=H, W=W, seed=7, device=dev)
+    img = scene.all_pix.view(n_pic, H, W, 3)
+    rgba = torch.cat((img, torch.ones(n_pic, H, W, 1)), -1).mul(255.0).round().to(torch.uint8).numpy()
+    mats = np.zeros((n_pic, 4, 4))
+    mats[:, 3, 3] = 1.0
+    mats[:, :3, :4] = scene.poses_bounds[:, :15].reshape(n_pic, 3, 5)[:, :, :4]
+    root = str(tmp_path) + "/lego/"
+    angle = 2.0 * np.arctan(0.5 * W / scene.focal)
+    for mode in ("train", "val", "test"):
+        write_blender_tree(root, mode, rgba, mats, angle)
+    os.makedirs(str(tmp_path) + "/conf", exist_ok=True)
+    with open(str(tmp_path) + "/conf/lego.ini", "w") as f:  # the reference's keys (conf/lego.ini) + the three it forgets
+        f.write(f"[lego]\nGPU = 0\nIMG_DIR = {root}\nRESULTS_PATH = {tmp_path}/results/\nCKPT_PATH = {tmp_path}/checkpoint/\nLOW_RES = 1\n"
+                "TOTAL_ITER = 24\nBATCH_RAY = 512\nLEARNING = 3e-4\nLR_GAMMA = 0.1\nLR_MILESTONE = [10, 200]\nN_COARSE = 64\nN_FINE = 128\n"
+                "DATA_TYPE = sync\nSTEP = 12\nDECAY_END = 10000\nSCHED = EXP\nCONTINUE = False\n")
+    monkeypatch.chdir(tmp_path)
+    conf = ConfigParser()
+    conf.read("./conf/" + "lego" + ".ini")
+    c = lambda k: conf.get("lego", k)
+    run_nerf = NeRFRunner(gpu=int(c("GPU")), img_dir=c("IMG_DIR"), results_path=c("RESULTS_PATH"), ckpt_path=c("CKPT_PATH"),
+                          low_res=int(c("LOW_RES")), total_iter=int(c("TOTAL_ITER")), batch_ray=int(c("BATCH_RAY")),
+                          learning=float(c("LEARNING")), lr_gamma=float(c("LR_GAMMA")), lr_milestone=list(c("LR_MILESTONE")),
+                          n_coarse=int(c("N_COARSE")), n_fine=int(c("N_FINE")), data_type=c("DATA_TYPE"), step=int(c("STEP")),
+                          decay_end=float(c("DECAY_END")), sched=c("SCHED"), continue_=eval(c("CONTINUE")))
+    run_nerf.trainer()
+    frames = run_nerf.display()
+    assert run_nerf.last_iter == 23 and len(glob.glob(str(tmp_path) + "/checkpoint/*.pkl")) == 2
+    assert frames.shape == (n_pic, H, W, 3) and len(glob.glob(str(tmp_path) + "/results/*/*.jpg")) == n_pic
+    # frame 0 against the oracle: the display loop's batches are rays [g*512, (g+1)*512) of the unshuffled pixel list
+    w = {k: v.detach().cpu().clone() for k, v in run_nerf.model.state_dict().items()}
+    ds = run_nerf.disp_dataset
+    want = np.ones((H, W, 3), dtype=np.float32)
+    for s in range(0, H * W, 512):
+        items = [ds[i] for i in range(s, s + 512)]
+        row = torch.tensor([it[0] for it in items]); col = torch.tensor([it[1] for it in items])
+        pb = torch.from_numpy(np.stack([it[3] for it in items]))
+        with torch.no_grad():
+            _, of = oracle.render(w, row, col, pb, run_nerf.K_inv, 64, 128)
+        want[row.numpy(), col.numpy()] = of.numpy()
+    e = max_rel(frames[0], want)
+    print(f"displayed frame vs oracle render: max-rel {e:.2e}")
+    assert e < 1e-4

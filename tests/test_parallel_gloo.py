@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
         for p, g in zip(params, base):
             p.grad = (rank + 1) * g.clone()
         b = par.GradBucket(params)
-        assert b.flat.numel() == 593924
+        assert b.numel == 593924 and b.numel <= b.flat.numel() < b.numel + 64 * 24 and all((v.data_ptr() - b.flat.data_ptr()) % 256 == 0 for v in b.views)
         b.allreduce_sum()
         tot = sum(range(1, world + 1))
         ok = all(torch.allclose(p.grad, tot * g, rtol=1e-6, atol=1e-7) for p, g in zip(params, base))

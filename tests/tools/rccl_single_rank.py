@@ -1,0 +1,94 @@
+"""Child process of tests/test_gpu_parallel.py: the data-parallel train step over a REAL RCCL process group (backend "nccl"
+on ROCm) with one rank on cuda:0.  Exercises what the multi-GPU job does per rank: GradBucket on device tensors, backward
+kernels writing straight into the flat buffer, the SUM all-reduce through RCCL, parallel.train_step_sharded.
+
+    python tests/tools/rccl_single_rank.py          (prints "RCCL-OK ..." and exits 0)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import torch
+import torch.distributed as dist
+
+import nerf_oracle as O
+import nerf_tiny_amd as P
+from nerf_tiny_amd import parallel as par
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29641")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    assert dist.get_backend() == "nccl"
+    B, Nc, Nf = 512, 64, 128
+    row, col, pb, K, Ct = O.fern_inputs(B, seed=21)
+    w = O.make_weights(7, sharp=True)
+    row, col, pbd, Ctd = row.to(dev), col.to(dev), pb.to(dev), Ct.to(dev)
+
+    def model(n):
+        m = P.NeRFModel(Nc, Nf, n)
+        m.load_state_dict(w)
+        return m.to(dev)
+
+    # (a) plain autograd path, no bucket
+    m = model(B)
+    Cc, Cf = m(row, col, pbd, K)
+    m.ray_loss(Cc, Cf, Ctd).backward()
+    ref = [p.grad.detach().clone() for p in m.network.parameters()]
+
+    # (b) the sharded step on the full batch (world 1): gradients land in the flat bucket, go through RCCL, stay bit-identical
+    m1 = model(B)
+    bucket = par.GradBucket(m1.network.parameters())
+    par.train_step_sharded(m1, bucket, row, col, pbd, K, Ctd, rank=0, world=1)
+    torch.cuda.synchronize()
+    for p, v, r in zip(m1.network.parameters(), bucket.views, ref):
+        assert p.grad.data_ptr() == v.data_ptr(), "p.grad must alias the flat all-reduce buffer"
+        assert torch.equal(p.grad, r), "bucketed gradient differs from the plain autograd gradient"
+    used = torch.zeros_like(bucket.flat, dtype=torch.bool)
+    for v in bucket.views:
+        used[(v.data_ptr() - bucket.flat.data_ptr()) // 4:][: v.numel()] = True
+    assert int(used.sum()) == 593924 and float(bucket.flat[~used].abs().max()) == 0.0
+    assert m1.grad_bucket is None and m1.ray0_near_far is None  # restored
+
+    # a second step overwrites (does not accumulate) -- the C ABI's semantics, like zero_grad() + backward()
+    par.train_step_sharded(m1, bucket, row, col, pbd, K, Ctd, rank=0, world=1)
+    for p, r in zip(m1.network.parameters(), ref):
+        assert torch.equal(p.grad, r)
+
+    # (c) two shards of the same batch, each through train_step_sharded (the all-reduce of this 1-rank group is the identity):
+    # their flat buffers add up to the full-batch gradient (loss = SUM over rays, global ray 0 handed to both)
+    m2 = model(B // 2)
+    flats = []
+    for r in range(2):
+        b2 = par.GradBucket(m2.network.parameters())
+        par.train_step_sharded(m2, b2, row, col, pbd, K, Ctd, rank=r, world=2)
+        flats.append(b2)
+    for x, y, f in zip(flats[0].views, flats[1].views, ref):
+        scale = float(x.double().norm() + y.double().norm())
+        assert float((x.double() + y.double() - f.double()).norm()) < 2e-5 * scale
+
+    # (d) the bf16-MLP variant takes the same route
+    m1.bf16_mlp = True
+    par.train_step_sharded(m1, bucket, row, col, pbd, K, Ctd, rank=0, world=1)
+    assert all(torch.isfinite(p.grad).all() for p in m1.network.parameters())
+    assert not torch.equal(m1.network.point_info.weight.grad, ref[18])
+
+    # (e) the fused optimizer steps from the bucket views
+    opt = P.FusedAdam(list(m1.network.parameters()), lr=1e-3)
+    before = m1.network.point_info.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m1.network.point_info.weight)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RCCL-OK single-rank nccl group: bucketed backward, all-reduce, shard sum, bf16, fused Adam")
+
+
+if __name__ == "__main__":
+    main()
