@@ -51,6 +51,42 @@ int check_sizes(int B, int Nc, int Nf) {
 // wave blocks (32 samples) of one pass of the bf16 kernels: whole 256-sample workgroups
 size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 
+
+// The twelve weight-gradient products of the fp32 train step (dw_f32.hip) with their slab offsets; pointers are filled in
+// by nerf_hip_backward (null here: only sizes matter for the layout).
+int build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw) {
+  memset(&b, 0, sizeof(b));
+  long long off = 0;
+  auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db) -> DwItem& {
+    DwItem& it = b.item[b.n++];
+    it.G = g; it.X = x; it.nout = nout; it.nin = nin; it.nin_real = nin_real; it.dW = dW; it.ldw = ldw; it.col0 = col0; it.db = db;
+    it.slab_off = off;
+    off += (long long)dw_item_slab_floats(it);
+    return it;
+  };
+  auto Gt = [&](int t) { return G ? G + (size_t)t * MS : nullptr; };
+  auto St = [&](int t) { return save ? save + (size_t)t * MS : nullptr; };
+  auto D = [&](int i) { return dw ? dw[i] : nullptr; };
+  add(Gt(0), 256, St(S_GP), 64, POINT_DIM, D(0), POINT_DIM, 0, D(1));                          // layer 0: X = gamma_p
+  for (int l = 1; l <= 7; ++l)                                                                   // layers 1..7 (layer 4: hidden columns)
+    add(Gt(l), 256, St(l - 1), 256, 256, D(2 * l), l == 4 ? WIDTH + POINT_DIM : WIDTH, 0, D(2 * l + 1));
+  add(Gt(4), 256, St(S_GP), 64, POINT_DIM, D(8), WIDTH + POINT_DIM, WIDTH, nullptr);            // layer 4, skip columns
+  add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI));                              // point_info
+  add(Gt(G_D), 128, St(S_FEAT), 256, 256, D(W_DIR), WIDTH + DIR_DIM, DIR_DIM, D(B_DIR));        // dir_info, feature columns
+  DwItem& th = add(dz4, 32, St(7), 384, 384, D(W_COLOR), HALF, 0, D(B_COLOR));                  // colour + sigma heads: X = [h7 | c]
+  th.thin = 1; th.X2 = St(S_C); th.dW2 = D(W_SIGMA); th.db2 = D(B_SIGMA);
+  // (thin was flagged after add(): its slab size is smaller than add() assumed -- harmless, it is the last item)
+  return b.n;
+}
+
+size_t dw_batch_slab_floats() {
+  DwBatch b;
+  build_dw_batch(b, nullptr, nullptr, nullptr, 0, nullptr);
+  const DwItem& last = b.item[b.n - 1];
+  DwItem full = last; full.thin = 0; full.nout = 256; full.nin = 256;  // upper bound for the last item
+  return (size_t)last.slab_off + dw_item_slab_floats(full);
+}
+
 WsLayout layout(int B, int Nc, int Nf, int flags) {
   flags &= ~NERF_HIP_WEIGHTS_UNCHANGED;  // not a layout property
   WsLayout L;
@@ -59,6 +95,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
   L.status = take(256);
+  L.dbg = take(DBG_WORDS * 8);  // diagnostic builds (-DNERF_STAMPS) write cycle stamps here; untouched otherwise
   L.packed = take((size_t)PACKED_ALL_F4 * 16);
   if (flags & NERF_HIP_BF16_MLP) L.packed_bf = take(BF_IMAGE_BYTES);
   L.rayf = take(b * RAYF * 4);
@@ -85,12 +122,12 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
       L.bG = take(wb * BG_TOTAL_KS * BF_FRAG_BYTES);
       L.bslabs = take(dw_bf16_slab_floats() * 4);
     } else {
-      L.save = take((size_t)NSAVE * Mtot * WIDTH * 4);
+      L.save = take((size_t)NSAVE * (Mtot + DUMP_ROWS) * WIDTH * 4);  // + dump rows (kernels.h: MSrows)
       L.masks = take((size_t)8 * tiles * 4 * 256 * 2);
-      L.G = take((size_t)NGRAD * Mtot * WIDTH * 4);
+      L.G = take((size_t)NGRAD * (Mtot + DUMP_ROWS) * WIDTH * 4);
       L.dz = take(Mtot * 16);
       L.dspre = take(Mtot * 4);
-      L.slabs = take(dw_slab_floats_max() * 4);
+      L.slabs = take(dw_batch_slab_floats() * 4);  // every product of the step keeps its own slabs: ONE reduce launch at the end
       L.sbuf = take(b * HALF * 4);
       L.gdbuf = take(b * DIR_DIM * 4);
     }
@@ -234,12 +271,12 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.sigma = at<float>(ws, L.sig_c);
   fa.N = Nc; fa.M = B * Nc;
 #ifdef NERF_STAMPS
-  fa.stamps = at<unsigned long long>(ws, L.status) + 8;  // diagnostic build: cycle sums live behind the status word
+  fa.stamps = at<unsigned long long>(ws, L.dbg);  // diagnostic build: cycle sums per phase, words [0, 32)
 #endif
   const int tiles_c = (B * Nc + TM - 1) / TM, tiles_f = (B * Nf + TM - 1) / TM;
   if (save) {
     fa.spre = at<float>(ws, L.spre);
-    fa.row0 = 0; fa.tile0 = 0; fa.tiles_tot = tiles_c + tiles_f; fa.Mtot = (long long)B * (Nc + Nf);
+    fa.row0 = 0; fa.tile0 = 0; fa.tiles_tot = tiles_c + tiles_f; fa.Mtot = (long long)B * (Nc + Nf); fa.MSrows = fa.Mtot + DUMP_ROWS;
     if (bf16) {
       fa.bsave = at<unsigned char>(ws, L.bsave); fa.bmask = at<uint16_t>(ws, L.bmask);
       fa.wb0 = 0; fa.wb_tot = (int)(wave_blocks(B, Nc) + wave_blocks(B, Nf));
@@ -334,7 +371,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   const Weights24 w = as_w24(weights24);
   float* const* dw = dweights24;
   const long long Mtot = (long long)B * (Nc + Nf);
-  const size_t MS = (size_t)Mtot * WIDTH;
+  const size_t MS = (size_t)(Mtot + DUMP_ROWS) * WIDTH;  // tensor stride of save / G
   const int tiles_c = (B * Nc + TM - 1) / TM, tiles_f = (B * Nf + TM - 1) / TM;
   float* save = at<float>(ws, L.save);
   float* G = at<float>(ws, L.G);
@@ -362,7 +399,10 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     fb.save = save; fb.masks = at<uint16_t>(ws, L.masks);
     fb.G = G; fb.dz = at<float>(ws, L.dz); fb.dspre = at<float>(ws, L.dspre);
   }
-  fb.tiles_tot = tiles_c + tiles_f; fb.Mtot = Mtot;
+  fb.tiles_tot = tiles_c + tiles_f; fb.Mtot = Mtot; fb.MSrows = Mtot + DUMP_ROWS;
+#ifdef NERF_STAMPS
+  fb.stamps = at<unsigned long long>(ws, L.dbg) + 32;
+#endif
   fb.t = at<float>(ws, L.t_f); fb.rgb = at<float>(ws, L.rgb_f);
   fb.drgb = at<float>(ws, L.drgb_f); fb.dsig = at<float>(ws, L.dsig_f); fb.dt = at<float>(ws, L.dt_f);
   fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf; fb.wb0 = wb_c;
@@ -426,39 +466,22 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA], st));
   } else {
     ProfScope ps(NERF_HIP_K_BWD_DW, st);
-    DwProblem p;
-    memset(&p, 0, sizeof(p));
-    p.Mtot = Mtot; p.slabs = at<float>(ws, L.slabs); p.ldg = WIDTH; p.ldx = WIDTH;
-    // layer 0: X = gamma_p
-    p.G = G + 0 * MS; p.nout = 256; p.X = save + S_GP * MS; p.nin = 64; p.nin_real = POINT_DIM;
-    p.dW = dw[0]; p.ldw = POINT_DIM; p.col0 = 0; p.db = dw[1];
-    HIP_TRY(launch_dw(p, st));
-    for (int l = 1; l <= 7; ++l) {
-      p.G = G + (size_t)l * MS; p.X = save + (size_t)(l - 1) * MS; p.nin = 256; p.nin_real = 256;
-      p.dW = dw[2 * l]; p.ldw = (l == 4) ? WIDTH + POINT_DIM : WIDTH; p.col0 = 0; p.db = dw[2 * l + 1];
-      HIP_TRY(launch_dw(p, st));
+    DwBatch batch;
+    build_dw_batch(batch, G, save, at<float>(ws, L.dz), MS, dw);
+    float* slabs = at<float>(ws, L.slabs);
+    batch.slabs = slabs;
+    for (int i = 0; i < batch.n; ++i) {
+#ifdef NERF_STAMPS
+      batch.item[i].stamps = at<unsigned long long>(ws, L.dbg) + 64;
+#endif
+      HIP_TRY(launch_dw(batch.item[i], Mtot, slabs, st));
     }
-    // layer 4, skip columns
-    p.G = G + 4 * MS; p.X = save + S_GP * MS; p.nin = 64; p.nin_real = POINT_DIM;
-    p.dW = dw[8]; p.ldw = WIDTH + POINT_DIM; p.col0 = WIDTH; p.db = nullptr;
-    HIP_TRY(launch_dw(p, st));
-    // point_info
-    p.G = G + G_PI * MS; p.X = save + 7 * MS; p.nin = 256; p.nin_real = 256;
-    p.dW = dw[W_PI]; p.ldw = WIDTH; p.col0 = 0; p.db = dw[B_PI];
-    HIP_TRY(launch_dw(p, st));
-    // dir_info, feature columns
-    p.G = G + G_D * MS; p.nout = 128; p.X = save + S_FEAT * MS; p.nin = 256; p.nin_real = 256;
-    p.dW = dw[W_DIR]; p.ldw = WIDTH + DIR_DIM; p.col0 = DIR_DIM; p.db = dw[B_DIR];
-    HIP_TRY(launch_dw(p, st));
-    // thin heads
-    HIP_TRY(hipMemsetAsync(dw[W_SIGMA], 0, WIDTH * 4, st));
-    HIP_TRY(hipMemsetAsync(dw[B_SIGMA], 0, 4, st));
-    HIP_TRY(hipMemsetAsync(dw[W_COLOR], 0, 3 * HALF * 4, st));
-    HIP_TRY(hipMemsetAsync(dw[B_COLOR], 0, 3 * 4, st));
+    HIP_TRY(launch_dw_reduce(batch, st));
+    // direction-encoding columns of dir_info (per-ray sums)
     SmallGradArgs sg;
     memset(&sg, 0, sizeof(sg));
     sg.save = save; sg.G = G; sg.dz = at<float>(ws, L.dz); sg.dspre = at<float>(ws, L.dspre); sg.rayf = at<float>(ws, L.rayf);
-    sg.Mtot = Mtot; sg.B = B; sg.Nc = Nc; sg.Nf = Nf;
+    sg.Mtot = Mtot; sg.MSrows = Mtot + DUMP_ROWS; sg.B = B; sg.Nc = Nc; sg.Nf = Nf;
     sg.dW_color = dw[W_COLOR]; sg.db_color = dw[B_COLOR]; sg.dw_sigma = dw[W_SIGMA]; sg.db_sigma = dw[B_SIGMA]; sg.dW_dir = dw[W_DIR];
     sg.sbuf = at<float>(ws, L.sbuf); sg.gdbuf = at<float>(ws, L.gdbuf);
     HIP_TRY(launch_small_grads(sg, st));
@@ -471,7 +494,7 @@ int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_
   if (int rc = check_sizes(B, Nc, Nf)) return rc;
   const WsLayout L = layout(B, Nc, Nf, flags);
   struct { const char* n; size_t o; } tab[] = {
-      {"status", L.status}, {"packed", L.packed}, {"packed_bf", L.packed_bf}, {"bsave", L.bsave}, {"bmask", L.bmask}, {"bG", L.bG}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
+      {"status", L.status}, {"dbg", L.dbg}, {"packed", L.packed}, {"packed_bf", L.packed_bf}, {"bsave", L.bsave}, {"bmask", L.bmask}, {"bG", L.bG}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
       {"rgb_c", L.rgb_c}, {"w_c", L.w_c}, {"t_f", L.t_f}, {"sig_f", L.sig_f}, {"rgb_f", L.rgb_f}, {"perm", L.perm},
       {"w_m", L.w_m}, {"bundle", L.bundle}, {"save", L.save}, {"masks", L.masks}, {"spre", L.spre}, {"G", L.G}, {"dz", L.dz},
       {"dspre", L.dspre}, {"drgb_c", L.drgb_c}, {"dsig_c", L.dsig_c}, {"drgb_f", L.drgb_f}, {"dsig_f", L.dsig_f},

@@ -14,6 +14,8 @@ constexpr int L_POINT = 10;
 constexpr int L_DIR = 4;
 constexpr int HALF = 128;       // width of the colour branch (nerf.py:98)
 constexpr int TM = 64;          // samples per workgroup tile of the field kernels
+constexpr int DBG_WORDS = 16384;   // u64 words of the workspace's diagnostic area (make stamps)
+constexpr int DUMP_ROWS = 64;   // extra rows behind every saved tensor / gradient buffer: lanes past the end of a pass store there, unpredicated
 constexpr int RAYF = 24;        // floats per ray record
 
 // Ray record (one per ray, written by k_rays):
@@ -60,7 +62,7 @@ struct Grads24 { float* p[24]; };
 
 // ---- workspace carve-up (host side, api.cpp) ----
 struct WsLayout {
-  size_t status, packed, packed_bf, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
+  size_t status, dbg, packed, packed_bf, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
   // training-only
   size_t packed_bf_bwd, bsave, bmask, bG, bslabs;  // bf16-MLP training (fragment layout, bf16_common.h)
   size_t perm, w_m, bundle, save, masks, spre, G, dz, dspre, drgb_c, dsig_c, drgb_f, dsig_f, dt_f, slabs, sbuf, gdbuf;

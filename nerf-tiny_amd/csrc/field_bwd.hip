@@ -7,14 +7,8 @@
 //                     FINE also back-propagates into the encoding inputs: d loss/d gamma_p (skip layer +
 //                     layer 0) -> d loss/d point -> d loss/d t_fine  (the reference does NOT detach t_fine,
 //                     nerf.py:259 -- quirk Q9).
-//  k_dw               dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM: the reduction
-//                     index is the sample, both operands are read straight from their row-major HBM images
-//                     (lane l <- columns 4(l&31)..+3 of G and 2(l&31)..+1 of X, rows m, m+1), one 128 x 64 output
-//                     block (128 accumulator VGPRs) per wave, 8 waves, one workgroup per CU, a branch-free
-//                     3-stage register rotation with pinned prefetches, per-wave partial slabs summed by
-//                     k_dw_reduce (deterministic; no float atomics).  Bias gradients (column sums of G) ride
-//                     along on the VALU.
-//  k_small_*          the thin heads: colour (3x128), sigma (1x256), direction encoding part of dir_info.
+//  k_dir_*            the direction-encoding columns of dir_info (per-ray sums of dpre_dir times gamma_d).
+//  (the weight-gradient GEMMs incl. the colour / sigma heads: dw_f32.hip)
 //
 // Autograd spans replaced: backward of Network.forward (nerf.py:101-124), Encoder.forward (nerf.py:135-167)
 // and the sample-point arithmetic (nerf.py:200-216) as invoked by loss.backward() at nerf.py:473.
@@ -85,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
   const int mc = valid ? m : a.M - 1;
   const int nrows = (a.M - m0) < TM ? (a.M - m0) : TM;
   const long long grow0 = (long long)a.row0 + m0;
-  const size_t MS = (size_t)a.Mtot * WIDTH;
+  const size_t MS = (size_t)a.MSrows * WIDTH;
   const uint16_t* mk = a.masks + ((size_t)(a.tile0 + blockIdx.x) * 4) * 256 + tid;
   const size_t MKS = (size_t)a.tiles_tot * 4 * 256;
   const int fbase = wv * 64;
@@ -132,7 +126,10 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
     const float sp = a.spre[a.row0 + mc];
     const float sgn = sp > 0.f ? 1.0f : (sp < 0.f ? -1.0f : 0.f);  // d|x|/dx with sign(0) = 0 like torch
     const float ds = valid ? a.dsig[mc] * sgn : 0.f;
-    if (wv == 0 && valid) a.dspre[a.row0 + m] = ds;
+    if (wv == 0 && valid) {
+      a.dspre[a.row0 + m] = ds;
+      a.dz[(size_t)(a.row0 + m) * 4 + 3] = ds;  // (dz_r, dz_g, dz_b, dsigma_pre): A operand of the thin-heads product (dw_f32.hip)
+    }
     const int j = lane & 31, h = lane >> 5;
     const float ds0 = __shfl(ds, j), ds1 = __shfl(ds, j + 32);
     const float* ws = a.w.p[W_SIGMA];
@@ -237,219 +234,12 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight-gradient GEMM
+// direction-encoding columns of dir_info (the weight-gradient GEMMs and the thin heads live in dw_f32.hip)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
-__device__ __forceinline__ float comp(const float2& v, int c) { return c == 0 ? v.x : v.y; }
-
-constexpr int DW_UNROLL = 4;   // k-steps (row pairs) per pipeline stage
-constexpr int DW_STAGES = 3;   // register stages in flight (2 prefetched ahead of the one being multiplied)
-constexpr int DW_CB = 2;       // B components per lane: a wave owns a 128 (out) x 64 (in) block
-constexpr int DW_WAVES = 8;    // 512 threads, two waves per SIMD
-
-struct DwStage {
-  float4 a[DW_UNROLL];
-  float2 b[DW_UNROLL];
-};
-
-// main loop of k_dw over rows [r_begin, r_end).  CHECK = false: every row of every stage is in range (no selects
-// between the loads and their use, so the loads of two stages stay in flight behind the MFMAs of the third).
-template <bool CHECK>
-__device__ __forceinline__ void dw_rows(const DwProblem& p, const float* __restrict__ gp, const float* __restrict__ xp, long long r_begin,
-                                        long long r_end, int h, bool do_bias, f32x16 (&acc)[4][DW_CB], float (&bsum)[4]) {
-  auto load = [&](long long r0, DwStage& S) {
-#pragma unroll
-    for (int u = 0; u < DW_UNROLL; ++u) {
-      // both operands have row stride WIDTH floats (all buffers of the workspace do)
-      if (CHECK) {
-        long long r = r0 + 2 * u + h;
-        r = r < r_end ? r : r_end - 1;
-        S.a[u] = *reinterpret_cast<const float4*>(gp + (size_t)r * WIDTH);
-        S.b[u] = *reinterpret_cast<const float2*>(xp + (size_t)r * WIDTH);
-      } else {
-        const size_t off = (size_t)(r0 + h) * WIDTH + (size_t)u * 2 * WIDTH;
-        S.a[u] = *reinterpret_cast<const float4*>(gp + off);
-        S.b[u] = *reinterpret_cast<const float2*>(xp + off);
-      }
-    }
-  };
-  auto mul = [&](long long r0, const DwStage& S) {
-#pragma unroll
-    for (int u = 0; u < DW_UNROLL; ++u) {
-      float4 a = S.a[u];
-      if (CHECK) {
-        if (r0 + 2 * u + h >= r_end) a = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the end contribute nothing
-      }
-#pragma unroll
-      for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-        for (int cb = 0; cb < DW_CB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(S.b[u], cb), acc[ca][cb], 0, 0, 0);
-      if (do_bias) {
-        bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w;
-      }
-    }
-  };
-  constexpr long long G = 2 * DW_UNROLL;  // rows per stage
-  DwStage s0, s1, s2;
-  // branch-free rotation: the two prefetches past the end re-read the last stage (valid memory, never multiplied)
-  const long long r_last = CHECK ? r_end : r_end - G;
-  auto at = [&](long long r) { return (CHECK || r <= r_last) ? r : r_last; };
-  load(r_begin, s0);
-  load(at(r_begin + G), s1);
-  for (long long r0 = r_begin; r0 < r_end; r0 += 3 * G) {
-    // the scheduling barriers keep each stage's requests where they are written: two stages (64 MFMAs) ahead of
-    // their use -- left alone the compiler sinks them next to the uses and every iteration waits on HBM
-    load(at(r0 + 2 * G), s2);
-    __builtin_amdgcn_sched_barrier(0);
-    mul(r0, s0);
-    __builtin_amdgcn_sched_barrier(0);
-    load(at(r0 + 3 * G), s0);
-    __builtin_amdgcn_sched_barrier(0);
-    mul(r0 + G, s1);
-    __builtin_amdgcn_sched_barrier(0);
-    load(at(r0 + 4 * G), s1);
-    __builtin_amdgcn_sched_barrier(0);
-    mul(r0 + 2 * G, s2);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// Slab layout per wave block: [cA 4][cB 2][reg 16][lane 64] floats; after the nout*nin block values come nout column sums.
-__global__ __launch_bounds__(512, 2) void k_dw(const DwProblem p) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int in_blocks = p.nin / 64;
-  const int nblocks = (p.nout / 128) * in_blocks;  // 8, 4 or 2
-  const int msubs = DW_WAVES / nblocks;
-  const int blk = wv % nblocks, msub = wv / nblocks;
-  const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * 64;
-  const long long gran = (long long)2 * DW_UNROLL * DW_STAGES * msubs;
-  const long long per_wg = ((p.Mtot + DW_WGS - 1) / DW_WGS + gran - 1) / gran * gran;
-  const long long per_wave = per_wg / msubs;  // a multiple of the 24 rows of one pipeline round
-  const long long r_begin = (long long)blockIdx.x * per_wg + (long long)msub * per_wave;
-  const long long r_nom = r_begin + per_wave;
-  const long long r_end = r_nom > p.Mtot ? p.Mtot : r_nom;
-  const int h = lane >> 5, q = lane & 31;
-
-  f32x16 acc[4][DW_CB];
-#pragma unroll
-  for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-    for (int cb = 0; cb < DW_CB; ++cb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = (p.db != nullptr) && (iB == 0);
-
-  const float* gp = p.G + oA + 4 * q;
-  const float* xp = p.X + iB + DW_CB * q;
-  if (r_begin < r_end) {
-    if (r_nom <= p.Mtot)
-      dw_rows<false>(p, gp, xp, r_begin, r_end, h, do_bias, acc, bsum);
-    else
-      dw_rows<true>(p, gp, xp, r_begin, r_end, h, do_bias, acc, bsum);
-  }
-  // write this wave's slab
-  const size_t slab_floats = (size_t)p.nout * p.nin + p.nout;
-  constexpr size_t wave_floats = (size_t)4 * DW_CB * 16 * 64;  // 128 x 64
-  float* slab = p.slabs + ((size_t)blockIdx.x * msubs + msub) * slab_floats;
-  float* ws = slab + (size_t)blk * wave_floats;
-#pragma unroll
-  for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-    for (int cb = 0; cb < DW_CB; ++cb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ws[((size_t)(ca * DW_CB + cb) * 16 + r) * 64 + lane] = acc[ca][cb][r];
-  if (do_bias) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) bsum[c] += __shfl_xor(bsum[c], 32);
-    if (h == 0) {
-      float* bs = slab + (size_t)p.nout * p.nin + oA;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) bs[4 * q + c] = bsum[c];
-    }
-  }
-}
-
-// sums the slabs and scatters into the nn.Linear-layout gradient
-__global__ __launch_bounds__(256) void k_dw_reduce(const DwProblem p, int nslabs) {
-  constexpr int CB = DW_CB;
-  const int total = p.nout * p.nin + (p.db ? p.nout : 0);
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const size_t slab_floats = (size_t)p.nout * p.nin + p.nout;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // nslabs is a multiple of 8: eight independent loads in flight
-  for (int k = 0; k < nslabs; k += 8) {
-    const float* q = p.slabs + (size_t)k * slab_floats + e;
-    const float v0 = q[0], v1 = q[slab_floats], v2 = q[2 * slab_floats], v3 = q[3 * slab_floats];
-    const float v4 = q[4 * slab_floats], v5 = q[5 * slab_floats], v6 = q[6 * slab_floats], v7 = q[7 * slab_floats];
-    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-    s0 += v4; s1 += v5; s2 += v6; s3 += v7;
-  }
-  const float s = (s0 + s1) + (s2 + s3);
-  if (e < p.nout * p.nin) {
-    const int wave_floats = 4 * CB * 16 * 64;
-    const int in_blocks = p.nin / (32 * CB);
-    const int blk = e / wave_floats;
-    int r = e - blk * wave_floats;
-    const int lane = r & 63; r >>= 6;
-    const int reg = r & 15; r >>= 4;
-    const int cb = r % CB, ca = r / CB;
-    const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * (32 * CB);
-    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    const int out = oA + 4 * i + ca;
-    const int in = iB + CB * (lane & 31) + cb;
-    if (in < p.nin_real) p.dW[(size_t)out * p.ldw + p.col0 + in] = s;
-  } else {
-    p.db[e - p.nout * p.nin] = s;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// thin heads
-// ------------------------------------------------------------------------------------------------
-// colour head (dW_c[3][128], db_c[3]) and sigma head (dw_sigma[256], db_sigma): plain VALU column reductions with
-// one float atomic per (workgroup, output).  Destinations must be zeroed beforehand.
-constexpr int SG_WGS = 4096;
-__global__ __launch_bounds__(256) void k_small_heads(const SmallGradArgs a) {
-  const int t = threadIdx.x;
-  const long long per = (a.Mtot + SG_WGS - 1) / SG_WGS;
-  const long long r0 = (long long)blockIdx.x * per;
-  long long r1 = r0 + per;
-  if (r1 > a.Mtot) r1 = a.Mtot;
-  const size_t MS = (size_t)a.Mtot * WIDTH;
-  const float* h7 = a.save + 7 * MS;
-  const float* cc = a.save + S_C * MS;
-  float as = 0.f, ac0 = 0.f, ac1 = 0.f, ac2 = 0.f, bs = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  for (long long r = r0; r < r1; ++r) {
-    const float ds = a.dspre[r];
-    const float4 dz = *reinterpret_cast<const float4*>(a.dz + (size_t)r * 4);
-    as = __builtin_fmaf(ds, h7[(size_t)r * WIDTH + t], as);
-    if (t < HALF) {
-      const float c = cc[(size_t)r * WIDTH + t];
-      ac0 = __builtin_fmaf(dz.x, c, ac0);
-      ac1 = __builtin_fmaf(dz.y, c, ac1);
-      ac2 = __builtin_fmaf(dz.z, c, ac2);
-    }
-    if (t == 0) { bs += ds; b0 += dz.x; b1 += dz.y; b2 += dz.z; }
-  }
-  atomicAdd(a.dw_sigma + t, as);
-  if (t < HALF) {
-    atomicAdd(a.dW_color + t, ac0);
-    atomicAdd(a.dW_color + HALF + t, ac1);
-    atomicAdd(a.dW_color + 2 * HALF + t, ac2);
-  }
-  if (t == 0) {
-    atomicAdd(a.db_sigma, bs);
-    atomicAdd(a.db_color + 0, b0);
-    atomicAdd(a.db_color + 1, b1);
-    atomicAdd(a.db_color + 2, b2);
-  }
-}
-
 // direction-encoding columns of dir_info: dW_d[o][k<24] = sum_ray gamma_d[ray][k] * sum_{samples of ray} dpre_d[m][o]
 __global__ __launch_bounds__(128) void k_dir_ray_sums(const SmallGradArgs a) {
   const int ray = blockIdx.x, t = threadIdx.x;
-  const size_t MS = (size_t)a.Mtot * WIDTH;
+  const size_t MS = (size_t)a.MSrows * WIDTH;
   const float* gd = a.G + G_D * MS;
   float s = 0.f;
   const size_t c0 = (size_t)ray * a.Nc, f0 = (size_t)a.B * a.Nc + (size_t)ray * a.Nf;
@@ -494,28 +284,7 @@ hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st) {
   return hipGetLastError();
 }
 
-size_t dw_slab_floats(int nout, int nin) {
-  const int nblocks = (nout / 128) * (nin / 64);
-  return (size_t)DW_WGS * (DW_WAVES / nblocks) * ((size_t)nout * nin + nout);
-}
-size_t dw_slab_floats_max() {
-  size_t a = dw_slab_floats(256, 256), b = dw_slab_floats(128, 256), c = dw_slab_floats(256, 64);
-  return a > b ? (a > c ? a : c) : (b > c ? b : c);
-}
-
-hipError_t launch_dw(const DwProblem& p, hipStream_t st) {
-  const int nblocks = (p.nout / 128) * (p.nin / 64);
-  const int msubs = DW_WAVES / nblocks;
-  hipLaunchKernelGGL(k_dw, dim3(DW_WGS), dim3(512), 0, st, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  const int total = p.nout * p.nin + (p.db ? p.nout : 0);
-  hipLaunchKernelGGL(k_dw_reduce, dim3((total + 255) / 256), dim3(256), 0, st, p, DW_WGS * msubs);
-  return hipGetLastError();
-}
-
 hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_small_heads, dim3(SG_WGS), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_dir_ray_sums, dim3(a.B), dim3(128), 0, st, a);
   hipLaunchKernelGGL(k_dir_gamma_zero, dim3(1), dim3(128), 0, st, a);
   hipLaunchKernelGGL(k_dir_gamma_dw, dim3(DIR_DIM, DG_CHUNKS), dim3(128), 0, st, a);

@@ -19,33 +19,46 @@ struct WStageB {
 
 __device__ __forceinline__ float f4cb(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
-// acc[f] (+)= sum_k Wt[f-tile][k] * in[k], in = prev tile values (MASK_IN: zeroed where the forward activation was not > 0;
-// mb[t] = mask word of input tile t).  grow != nullptr: the activated input (= this layer's pre-activation gradient) is
-// stored to G rows.  Two fragment stages as in k_field_fwd_reg; st0 = k-block 0 on entry / next segment's k-block 0 on exit.
-template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT, bool MASK_IN>
+// mask word of input tile t of one layer for this lane (forward kernel's layout: [layer][tile64][st][h*32 + j], entry (f, wv))
+__device__ __forceinline__ unsigned mask_word(const uint16_t* __restrict__ mlayer, int t) { return mlayer[((t & 1) * 2) * 256 + (t >> 1) * 64]; }
+
+// acc[f] (+)= sum_k Wt[f-tile][k] * in[k], in = prev tile values (MASK_IN: zeroed where the forward activation was not > 0).
+// Mask words are fetched LAZILY, one input tile (4 k-blocks = 8192 cycles) ahead of their use: `mfirst` holds the word of
+// tile 0 on entry; while tile t is activated the word of tile t+1 is requested, and during the last tile the word of tile 0
+// of the NEXT masked layer (`mnext`; HAS_NEXT_MASK = false: there is none) is requested into `mfirst` -- two live registers instead of eight, and no
+// load whose latency the wave has to sit out.  grow != nullptr: the activated input (= this layer's pre-activation gradient)
+// is stored to the G rows (lanes past the end of the pass own a dump row, so the stores carry no predicate).
+// Two fragment stages as in k_field_fwd_reg; st0 = k-block 0 on entry / next segment's k-block 0 on exit.
+template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT, bool MASK_IN, bool STORE = true, bool HAS_NEXT_MASK = MASK_IN>
 __device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
-                                              const f32x16* prev, f32x16* acc, WStageB<8>& st0, const unsigned* mb,
-                                              float* __restrict__ grow, bool live) {
+                                              const f32x16* prev, f32x16* acc, WStageB<8>& st0, const uint16_t* __restrict__ mlayer,
+                                              const uint16_t* __restrict__ mnext, unsigned& mfirst, float* __restrict__ grow) {
   constexpr int KT = KB / 4;
   const float4* sl = seg + lane;
   const float4* nl = next_seg + lane;
   WStageB<8> st1;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 tin[2];
+  unsigned mw = mfirst;  // word of the tile being activated
   auto activate = [&](int t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tin[t & 1][r] = MASK_IN ? (((mb[t] >> r) & 1u) ? prev[t][r] : 0.f) : prev[t][r];
-    if (grow != nullptr) {
-      if (live) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) =
-              make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));  // pin (see k_field_fwd_reg)
+    unsigned mn = 0;
+    if (MASK_IN) {
+      if (t + 1 < KT) mn = mask_word(mlayer, t + 1);
+      else if (HAS_NEXT_MASK) mfirst = mask_word(mnext, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tin[t & 1][r] = MASK_IN ? (((mw >> r) & 1u) ? prev[t][r] : 0.f) : prev[t][r];
+    // pin the activated tile to this program point (see k_field_fwd_reg), then stream it out: STORE is a compile-time
+    // property of the call, so the MFMA stream carries no pointer test
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));
+    if (STORE) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) =
+            make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
+    }
+    if (MASK_IN) mw = mn;
   };
   activate(0);
   // one k-block: request the fragments of k-block kb+1 (or of the next segment) into `ld`, multiply with `cur`
@@ -78,15 +91,35 @@ __device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, co
   }
 }
 
+#ifdef NERF_STAMPS  // diagnostic build only (make stamps): cycle sums per phase, see scripts/phase_stamps.py
+#define BSTAMP(slot)                                            \
+  do {                                                          \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    const unsigned long long t_ = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    tsum[slot] += t_ - tlast;                                   \
+    tlast = t_;                                                 \
+  } while (0)
+#else
+#define BSTAMP(slot) do { } while (0)
+#endif
+
 template <bool FINE>
 __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
+#ifdef NERF_STAMPS
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#endif
   const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * RMB;
   const int m = m0 + j;
   const bool valid = m < a.M;
   const int mc = valid ? m : a.M - 1;
-  const size_t MS = (size_t)a.Mtot * WIDTH;
-  const size_t grow_off = (size_t)(a.row0 + mc) * WIDTH + 4 * h;  // this lane's 16-byte groups start here
+  const size_t MS = (size_t)a.MSrows * WIDTH;
+  // this lane's row in the saved tensors / gradient buffers: lanes past the end of the pass own dump row Mtot + j (their
+  // gradients are exact zeros -- dz = ds = 0 below -- so what they store is harmless and what they read only has to be finite)
+  const long long rrow = valid ? (long long)(a.row0 + m) : a.Mtot + j;
+  const size_t grow_off = (size_t)rrow * WIDTH + 4 * h;  // this lane's 16-byte groups start here
   float* const grow = a.G + grow_off;
   const float* const srow = a.save + grow_off;
   const uint16_t* const mrow = a.masks + ((size_t)(a.tile0 + (m0 >> 6)) * 4 + ((m0 >> 5) & 1)) * 256 + h * 32 + j;
@@ -98,85 +131,108 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
   WStageB<8> st0;
 #pragma unroll
   for (int f = 0; f < 8; ++f) st0.w[f] = (wp + seg_off4(SEG_T_DIR) + lane)[(size_t)(f * 16) * 64];
+  auto mlayer = [&](int layer) { return mrow + (size_t)layer * MKS; };
+  unsigned mfirst = mask_word(mlayer(7), 0);  // first masked layer of the chain; every later word is fetched a tile ahead
 
-  auto load_masks = [&](int layer, unsigned (&mb)[8]) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) mb[t] = mrow[(size_t)layer * MKS + ((t & 1) * 2) * 256 + (t >> 1) * 64];
-  };
-
-  // ---- colour head backward (VALU): rgb = sigmoid(z), z = W_c c + b, c = relu(pre_d)  ->  dpre_d in registers
+  // ---- colour head backward (VALU): rgb = sigmoid(z), z = W_c c + b, c = relu(pre_d)  ->  dpre_d in registers.
+  // All loads first (the 16 c groups come from HBM): left to itself the compiler sinks the weight loads into per-element
+  // branches and the wave sits out sixteen dependent round trips before the first MFMA.
   f32x16 D0[4];
+  float ds;  // d loss / d sigma_pre of this lane's sample
   {
+    const float* crow = srow + S_C * MS;
+    float4 cv[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) cv[t][g] = *reinterpret_cast<const float4*>(crow + 32 * t + 8 * g);
     float dz[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float o = a.rgb[(size_t)mc * 3 + ch];
-      dz[ch] = valid ? a.drgb[(size_t)mc * 3 + ch] * ((1.0f - o) * o) : 0.f;
+      const float up = a.drgb[(size_t)mc * 3 + ch];
+      dz[ch] = valid ? up * ((1.0f - o) * o) : 0.f;
     }
-    if (valid && h == 0) *reinterpret_cast<float4*>(a.dz + (size_t)(a.row0 + m) * 4) = make_float4(dz[0], dz[1], dz[2], 0.f);
+    // sigma head upstream: sigma = |pre|, d|x|/dx with sign(0) = 0 like torch.  (dz_r, dz_g, dz_b, dsigma_pre) is the A operand
+    // of the thin-heads weight-gradient product (dw_f32.hip)
+    const float sp = a.spre[a.row0 + mc];
+    const float sgn = sp > 0.f ? 1.0f : (sp < 0.f ? -1.0f : 0.f);
+    ds = valid ? a.dsig[mc] * sgn : 0.f;
+    if (valid && h == 0) {
+      *reinterpret_cast<float4*>(a.dz + (size_t)(a.row0 + m) * 4) = make_float4(dz[0], dz[1], dz[2], ds);
+      a.dspre[a.row0 + m] = ds;
+    }
     const float* wc = a.w.p[W_COLOR] + 4 * h;
-    const float* crow = srow + S_C * MS;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+      float4 q0[4], q1[4], q2[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 cv = *reinterpret_cast<const float4*>(crow + 32 * t + 8 * g);
-        const float4 q0 = *reinterpret_cast<const float4*>(wc + 32 * t + 8 * g);
-        const float4 q1 = *reinterpret_cast<const float4*>(wc + HALF + 32 * t + 8 * g);
-        const float4 q2 = *reinterpret_cast<const float4*>(wc + 2 * HALF + 32 * t + 8 * g);
-        D0[t][4 * g + 0] = cv.x > 0.f ? __builtin_fmaf(q2.x, dz[2], __builtin_fmaf(q1.x, dz[1], q0.x * dz[0])) : 0.f;
-        D0[t][4 * g + 1] = cv.y > 0.f ? __builtin_fmaf(q2.y, dz[2], __builtin_fmaf(q1.y, dz[1], q0.y * dz[0])) : 0.f;
-        D0[t][4 * g + 2] = cv.z > 0.f ? __builtin_fmaf(q2.z, dz[2], __builtin_fmaf(q1.z, dz[1], q0.z * dz[0])) : 0.f;
-        D0[t][4 * g + 3] = cv.w > 0.f ? __builtin_fmaf(q2.w, dz[2], __builtin_fmaf(q1.w, dz[1], q0.w * dz[0])) : 0.f;
+        q0[g] = *reinterpret_cast<const float4*>(wc + 32 * t + 8 * g);
+        q1[g] = *reinterpret_cast<const float4*>(wc + HALF + 32 * t + 8 * g);
+        q2[g] = *reinterpret_cast<const float4*>(wc + 2 * HALF + 32 * t + 8 * g);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = __builtin_fmaf(q2[g].x, dz[2], __builtin_fmaf(q1[g].x, dz[1], q0[g].x * dz[0]));
+        const float v1 = __builtin_fmaf(q2[g].y, dz[2], __builtin_fmaf(q1[g].y, dz[1], q0[g].y * dz[0]));
+        const float v2 = __builtin_fmaf(q2[g].z, dz[2], __builtin_fmaf(q1[g].z, dz[1], q0[g].z * dz[0]));
+        const float v3 = __builtin_fmaf(q2[g].w, dz[2], __builtin_fmaf(q1[g].w, dz[1], q0[g].w * dz[0]));
+        D0[t][4 * g + 0] = cv[t][g].x > 0.f ? v0 : 0.f;
+        D0[t][4 * g + 1] = cv[t][g].y > 0.f ? v1 : 0.f;
+        D0[t][4 * g + 2] = cv[t][g].z > 0.f ? v2 : 0.f;
+        D0[t][4 * g + 3] = cv[t][g].w > 0.f ? v3 : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+  BSTAMP(0);  // prologue: colour head backward
   f32x16 A[8], B[8];
-  unsigned mb[8];
   // ---- dir_info backward: dfeat = W_d[:, 24:]^T dpre_d  (256 <- 128); stores dpre_d
-  reg_layer_bwd<16, 8, 32, 8, true, false>(wp + seg_off4(SEG_T_DIR), wp + seg_off4(SEG_T_PI), lane, D0, A, st0, nullptr,
-                                           grow + G_D * MS, valid);
+  reg_layer_bwd<16, 8, 32, 8, true, false>(wp + seg_off4(SEG_T_DIR), wp + seg_off4(SEG_T_PI), lane, D0, A, st0, nullptr, nullptr, mfirst,
+                                           grow + G_D * MS);
+  BSTAMP(1);  // dir_info (512 MFMAs)
   // ---- point_info backward + sigma head: dh7 = W_pi^T dfeat + w_sigma (x) dsigma_pre; stores dfeat
   {
-    const float sp = a.spre[a.row0 + mc];
-    const float sgn = sp > 0.f ? 1.0f : (sp < 0.f ? -1.0f : 0.f);  // d|x|/dx with sign(0) = 0 like torch
-    const float ds = valid ? a.dsig[mc] * sgn : 0.f;
-    if (valid && h == 0) a.dspre[a.row0 + m] = ds;
     const float dsb = (h == 0) ? ds : 0.f;  // outer product as one MFMA per tile: A = w_sigma rows, B = ds on lane half 0
     const float* ws = a.w.p[W_SIGMA];
 #pragma unroll
     for (int f = 0; f < 8; ++f) B[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[f * 32 + j], dsb, zero, 0, 0, 0);
   }
-  reg_layer_bwd<32, 8, 32, 8, false, false>(wp + seg_off4(SEG_T_PI), wp + seg_off4(SEG_T_L7), lane, A, B, st0, nullptr,
-                                            grow + G_PI * MS, valid);
+  reg_layer_bwd<32, 8, 32, 8, false, false>(wp + seg_off4(SEG_T_PI), wp + seg_off4(SEG_T_L7), lane, A, B, st0, nullptr, nullptr, mfirst,
+                                            grow + G_PI * MS);
+  BSTAMP(2);  // point_info + sigma head (1,032 MFMAs)
   // ---- layers 7, 6, 5: input = raw d h_l masked by h_l > 0 (= dpre_l, stored), output = raw d h_{l-1}
   const float4* const sT7 = wp + seg_off4(SEG_T_L7);
-  load_masks(7, mb);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7, sT7 + L256, lane, B, A, st0, mb, grow + 7 * MS, valid);
-  load_masks(6, mb);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + L256, sT7 + 2 * L256, lane, A, B, st0, mb, grow + 6 * MS, valid);
-  load_masks(5, mb);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + 2 * L256, wp + seg_off4(SEG_T_L4A), lane, B, A, st0, mb, grow + 5 * MS, valid);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7, sT7 + L256, lane, B, A, st0, mlayer(7), mlayer(6), mfirst, grow + 7 * MS);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + L256, sT7 + 2 * L256, lane, A, B, st0, mlayer(6), mlayer(5), mfirst, grow + 6 * MS);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + 2 * L256, wp + seg_off4(SEG_T_L4A), lane, B, A, st0, mlayer(5), mlayer(4), mfirst, grow + 5 * MS);
+  BSTAMP(3);  // layers 7..5 (3,072 MFMAs)
   // ---- layer 4 (input cat(h3, gamma_p)): d h3, and for the fine pass d gamma_p through the skip connection
   f32x16 accg[2];
-  load_masks(4, mb);
   if (FINE) {
-    reg_layer_bwd<32, 8, 32, 2, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L4B), lane, A, B, st0, mb, grow + 4 * MS, valid);
-    reg_layer_bwd<32, 2, 32, 8, true, true>(wp + seg_off4(SEG_T_L4B), wp + seg_off4(SEG_T_L3), lane, A, accg, st0, mb, nullptr, valid);
+    reg_layer_bwd<32, 8, 32, 2, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L4B), lane, A, B, st0, mlayer(4), mlayer(4), mfirst, grow + 4 * MS);
+    reg_layer_bwd<32, 2, 32, 8, true, true, false>(wp + seg_off4(SEG_T_L4B), wp + seg_off4(SEG_T_L3), lane, A, accg, st0, mlayer(4), mlayer(3), mfirst, nullptr);
   } else {
-    reg_layer_bwd<32, 8, 32, 8, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L3), lane, A, B, st0, mb, grow + 4 * MS, valid);
+    reg_layer_bwd<32, 8, 32, 8, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L3), lane, A, B, st0, mlayer(4), mlayer(3), mfirst, grow + 4 * MS);
   }
+  BSTAMP(4);  // layer 4 (1,024 / 1,280 MFMAs)
   // ---- layers 3, 2, 1
   const float4* const sT3 = wp + seg_off4(SEG_T_L3);
-  load_masks(3, mb);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3, sT3 + L256, lane, B, A, st0, mb, grow + 3 * MS, valid);
-  load_masks(2, mb);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3 + L256, sT3 + 2 * L256, lane, A, B, st0, mb, grow + 2 * MS, valid);
-  load_masks(1, mb);
-  reg_layer_bwd<32, 8, 32, 2, true, true>(sT3 + 2 * L256, FINE ? wp + seg_off4(SEG_T_L0) : nullptr, lane, B, A, st0, mb, grow + 1 * MS, valid);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3, sT3 + L256, lane, B, A, st0, mlayer(3), mlayer(2), mfirst, grow + 3 * MS);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3 + L256, sT3 + 2 * L256, lane, A, B, st0, mlayer(2), mlayer(1), mfirst, grow + 2 * MS);
+  unsigned mb0[8];  // coarse pass: the eight mask words of layer 0 for the epilogue, requested a whole layer ahead
+  if (!FINE) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) mb0[t] = mask_word(mlayer(0), t);
+  }
+  reg_layer_bwd<32, 8, 32, 2, true, true, true, FINE>(sT3 + 2 * L256, FINE ? wp + seg_off4(SEG_T_L0) : nullptr, lane, B, A, st0, mlayer(1),
+                                                      mlayer(0), mfirst, grow + 1 * MS);
+  BSTAMP(5);  // layers 3..1 (3,072 MFMAs)
   // ---- dpre_0 = d h0 masked; fine: d gamma_p += W_0^T dpre_0
-  load_masks(0, mb);
   if (FINE) {
-    reg_layer_bwd<32, 2, 32, 2, false, true>(wp + seg_off4(SEG_T_L0), nullptr, lane, A, accg, st0, mb, grow, valid);
+    reg_layer_bwd<32, 2, 32, 2, false, true, true, false>(wp + seg_off4(SEG_T_L0), nullptr, lane, A, accg, st0, mlayer(0), nullptr, mfirst, grow);
     // gamma -> point -> depth.  accg[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of pair pi = 4(4t+g) + 2h + e
     const int ray = mc / a.N;
     const float* rf = a.rayf + (size_t)ray * RAYF;
@@ -205,19 +261,26 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
       const float dtp = __builtin_fmaf(rf[RF_DWRD + 2], dp[2], __builtin_fmaf(rf[RF_DWRD + 1], dp[1], rf[RF_DWRD] * dp[0]));
       a.dt[m] += dtp;
     }
-  } else if (valid) {
+  } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 v;
-        v.x = ((mb[t] >> (4 * g + 0)) & 1u) ? A[t][4 * g + 0] : 0.f;
-        v.y = ((mb[t] >> (4 * g + 1)) & 1u) ? A[t][4 * g + 1] : 0.f;
-        v.z = ((mb[t] >> (4 * g + 2)) & 1u) ? A[t][4 * g + 2] : 0.f;
-        v.w = ((mb[t] >> (4 * g + 3)) & 1u) ? A[t][4 * g + 3] : 0.f;
+        v.x = ((mb0[t] >> (4 * g + 0)) & 1u) ? A[t][4 * g + 0] : 0.f;
+        v.y = ((mb0[t] >> (4 * g + 1)) & 1u) ? A[t][4 * g + 1] : 0.f;
+        v.z = ((mb0[t] >> (4 * g + 2)) & 1u) ? A[t][4 * g + 2] : 0.f;
+        v.w = ((mb0[t] >> (4 * g + 3)) & 1u) ? A[t][4 * g + 3] : 0.f;
         *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) = v;
       }
   }
+#ifdef NERF_STAMPS
+  BSTAMP(6);  // layer 0 / epilogue
+  if (a.stamps && lane == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(a.stamps + (FINE ? 8 : 0) + i, tsum[i]);
+    atomicAdd(a.stamps + (FINE ? 30 : 31), 1ull);
+  }
+#endif
 }
 
 hipError_t launch_field_bwd_reg(const FieldBwdArgs& a, bool fine, hipStream_t st) {

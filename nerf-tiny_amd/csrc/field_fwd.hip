@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   const float* rf = a.rayf + (size_t)ray * RAYF;
   const int nrows = (a.M - m0) < TM ? (a.M - m0) : TM;  // live rows of this tile
   const long long grow0 = (long long)a.row0 + m0;       // first row in the combined (coarse|fine) buffers
-  const size_t MS = (size_t)a.Mtot * WIDTH;              // stride between saved tensors
+  const size_t MS = (size_t)a.MSrows * WIDTH;              // stride between saved tensors
   uint16_t* mk = SAVE ? a.masks + ((size_t)(a.tile0 + blockIdx.x) * 4) * 256 + tid : nullptr;
   const size_t MKS = (size_t)a.tiles_tot * 4 * 256;      // stride between mask layers
 

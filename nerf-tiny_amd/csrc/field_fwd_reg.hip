@@ -31,6 +31,11 @@ __device__ __forceinline__ void stage_load(const float4* __restrict__ seg_lane, 
   for (int f = 0; f < NFT; ++f) s.w[f] = seg_lane[(size_t)(f * KB + kb) * 64];
 }
 
+// ReLU as ONE instruction: for every non-NaN float max(x, 0) = the float whose bits are max(int bits, 0) (negative floats and
+// -0 are negative integers).  fmaxf costs two (hipcc canonicalises its operand first), and next to fp32 MFMAs every VALU
+// instruction is matrix time lost (the fp32 MFMA runs on the SIMD's fp32 lanes).
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 // acc[f] (+)= sum_k W[f-tile][k] * act(prev)[k]   over KB k-blocks of 8.
@@ -45,15 +50,15 @@ __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v
 // Training (SAVE): the CONSUMER layer writes its activated input tiles to the row-major save buffer (lane (j, h) owns
 // the 16-byte groups 32t + 8g + 4h of row j) and, for ReLU inputs, the u16 mask words in the tile kernels' layout.
 struct SaveIn {
-  float* rows;      // &save[tensor][row0 + m0 + j][4h]   (null = nothing to save)
+  float* rows;      // &save[tensor][this lane's row][4h]   (null = nothing to save); lanes past the end of the pass own a dump
+                    // row behind the tensor (kernels.h: MSrows), so no store carries a predicate
   uint16_t* mask;   // &masks[layer][tile64][st][h*32 + j] (null = no masks); entry (f, wv) at + (f*2)*256 + wv*64
-  bool live;        // row inside the pass
 };
 
 template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT, bool RELU_IN, bool SAVE = false>
 __device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
                                           const f32x16* prev, f32x16* acc, WStage<8>& st0, const float* bv,
-                                          const SaveIn sv = SaveIn{nullptr, nullptr, false}) {
+                                          const SaveIn sv = SaveIn{nullptr, nullptr}) {
   constexpr int KT = KB / 4;
   const float4* sl = seg + lane;
   const float4* nl = next_seg + lane;
@@ -67,19 +72,19 @@ __device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const 
   f32x16 tin[2];
   auto activate = [&](int t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tin[t & 1][r] = RELU_IN ? fmaxf(prev[t][r], 0.f) : prev[t][r];
-    if (!SAVE) {
-      // pin the activated tile to this program point (the training variant's stores do that implicitly); without it
-      // the compiler hoists every tile's ReLU to the top of the layer and spills ~370 registers
+    for (int r = 0; r < 16; ++r) tin[t & 1][r] = RELU_IN ? (SAVE ? fmaxf(prev[t][r], 0.f) : relu1(prev[t][r])) : prev[t][r];  // (the training variant's register allocation falls apart with the integer form)
+    // pin the activated tile to this program point; without it the compiler hoists every tile's ReLU to the top of the
+    // layer and spills ~370 registers
 #pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));
-    }
-    if (SAVE && sv.rows != nullptr && sv.live) {
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));
+    if (SAVE) {  // compile-time: a SAVE layer always has rows, a SAVE && RELU_IN layer always has masks (no null tests in the stream)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(sv.rows + 32 * t + 8 * g) =
             make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
-      if (RELU_IN && sv.mask != nullptr) {
+      if (RELU_IN) {
+        // bit r = (prev > 0) = (relu'd value > 0): 0.0f - x is negative exactly then (+0 for either zero), and one
+        // v_alignbit shifts that sign bit into the word: 2 VALU per value instead of compare + select + or
         unsigned bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bits |= (prev[t][r] > 0.f) ? (1u << r) : 0u;
@@ -139,7 +144,7 @@ __device__ __forceinline__ void bias_load(const float* __restrict__ bias, int la
 template <bool SAVE, bool DEBUG>
 __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
 #ifdef NERF_STAMPS
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tsum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_readcyclecounter();
 #endif
   const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
@@ -192,12 +197,13 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   }
 
   // training: where this lane's rows / mask words go (rows of the coarse pass first, then the fine pass)
-  const size_t MS = (size_t)a.Mtot * WIDTH;
-  float* const srow = SAVE ? a.save + (size_t)(a.row0 + m) * WIDTH + 4 * h : nullptr;
+  const size_t MS = (size_t)a.MSrows * WIDTH;
+  const long long rrow = valid ? (long long)(a.row0 + m) : a.Mtot + j;  // lanes past the end: dump row
+  float* const srow = SAVE ? a.save + (size_t)rrow * WIDTH + 4 * h : nullptr;
   uint16_t* const mrow = SAVE ? a.masks + ((size_t)(a.tile0 + (m0 >> 6)) * 4 + ((m0 >> 5) & 1)) * 256 + h * 32 + j : nullptr;
   const size_t MKS = (size_t)a.tiles_tot * 4 * 256;
-  auto sv_rows = [&](int tensor) { return SaveIn{SAVE ? srow + (size_t)tensor * MS : nullptr, nullptr, valid}; };
-  auto sv_relu = [&](int layer) { return SaveIn{SAVE ? srow + (size_t)layer * MS : nullptr, SAVE ? mrow + (size_t)layer * MKS : nullptr, valid}; };
+  auto sv_rows = [&](int tensor) { return SaveIn{SAVE ? srow + (size_t)tensor * MS : nullptr, nullptr}; };
+  auto sv_relu = [&](int layer) { return SaveIn{SAVE ? srow + (size_t)layer * MS : nullptr, SAVE ? mrow + (size_t)layer * MKS : nullptr}; };
 
   RSTAMP(0);  // prologue: ray / depth loads, sample point, positional encoding
   // two accumulator sets ping-pong: a layer reads the previous layer's raw accumulators (ReLU applied lazily)
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   // ---- layer 0: gamma_p 60(64) -> 256
   bias_load<8>(a.w.p[B_L0], lane, bv);
   reg_layer<8, 8, 32, 8, true, false, SAVE>(wp + seg_off4(SEG_L0), sL1, lane, gp, A, st0, bv, sv_rows(S_GP));
+  RSTAMP(1);  // layer 0 (264 MFMAs)
   // ---- layers 1..3 (the segment after L3 is L4A: same shape)
   bias_load<8>(a.w.p[3], lane, bv);
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1, sL1 + L256, lane, A, B, st0, bv, sv_relu(0));
@@ -217,10 +224,12 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1 + L256, sL1 + 2 * L256, lane, B, A, st0, bv, sv_relu(1));
   bias_load<8>(a.w.p[7], lane, bv);
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1 + 2 * L256, wp + seg_off4(SEG_L4A), lane, A, B, st0, bv, sv_relu(2));
+  RSTAMP(2);  // layers 1..3 (3,096 MFMAs)
   // ---- layer 4: cat(h3, gamma_p), hidden first (nerf.py:109)
   bias_load<8>(a.w.p[9], lane, bv);
   reg_layer<32, 8, 8, 8, true, true, SAVE>(wp + seg_off4(SEG_L4A), wp + seg_off4(SEG_L4B), lane, B, A, st0, bv, sv_relu(3));
   reg_layer<8, 8, 32, 8, false, false>(wp + seg_off4(SEG_L4B), sL5, lane, gp, A, st0, nullptr);
+  RSTAMP(3);  // layer 4 (1,288 MFMAs)
   // ---- layers 5..7 (the segment after L7 is point_info: same shape)
   bias_load<8>(a.w.p[11], lane, bv);
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5, sL5 + L256, lane, A, B, st0, bv, sv_relu(4));
@@ -228,21 +237,33 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + L256, sL5 + 2 * L256, lane, B, A, st0, bv, sv_relu(5));
   bias_load<8>(a.w.p[15], lane, bv);
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + 2 * L256, wp + seg_off4(SEG_PI), lane, A, B, st0, bv, sv_relu(6));
-  RSTAMP(1);  // layers 0..7 (8,320 MFMAs = 532,480 cycles at the issue rate)
+  RSTAMP(4);  // layers 5..7 (3,096 MFMAs)
   // ---- sigma head on h7 = relu(B) (VALU): sigma = |w_sigma . h7 + b|  (nerf.py:94, 115)
   {
     const float* ws = a.w.p[W_SIGMA] + 4 * h;
     float s = 0.f;
+    // weights one tile ahead of their use, in explicit groups: under the register pressure of the training variant the
+    // compiler otherwise issues the 32 loads one at a time, each followed by a full wait
+    float4 wq[2][4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int g = 0; g < 4; ++g) wq[0][g] = *reinterpret_cast<const float4*>(ws + 8 * g);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t + 1 < 8) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wq[(t + 1) & 1][g] = *reinterpret_cast<const float4*>(ws + 32 * (t + 1) + 8 * g);
+      }
+      if (SAVE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 wq = *reinterpret_cast<const float4*>(ws + 32 * t + 8 * g);
-        s = __builtin_fmaf(fmaxf(B[t][4 * g + 0], 0.f), wq.x, s);
-        s = __builtin_fmaf(fmaxf(B[t][4 * g + 1], 0.f), wq.y, s);
-        s = __builtin_fmaf(fmaxf(B[t][4 * g + 2], 0.f), wq.z, s);
-        s = __builtin_fmaf(fmaxf(B[t][4 * g + 3], 0.f), wq.w, s);
+        const float4 q = wq[t & 1][g];
+        s = __builtin_fmaf(relu1(B[t][4 * g + 0]), q.x, s);
+        s = __builtin_fmaf(relu1(B[t][4 * g + 1]), q.y, s);
+        s = __builtin_fmaf(relu1(B[t][4 * g + 2]), q.z, s);
+        s = __builtin_fmaf(relu1(B[t][4 * g + 3]), q.w, s);
       }
+      if (SAVE) __builtin_amdgcn_sched_barrier(0);
+    }
     s += __shfl_xor(s, 32);
     if (valid && h == 0) {
       const float pre = s + a.w.p[B_SIGMA][0];
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
       if (SAVE) a.spre[a.row0 + m] = pre;
     }
   }
-  RSTAMP(2);  // sigma head
+  RSTAMP(5);  // sigma head
   // ---- point_info: 256 -> 256, no activation; next segment = dir_info (4 tiles)
   bias_load<8>(a.w.p[B_PI], lane, bv);
   reg_layer<32, 8, 32, 4, true, true, SAVE>(wp + seg_off4(SEG_PI), wp + seg_off4(SEG_DIR), lane, B, A, st0, bv, sv_relu(7));
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
       }
   }
   reg_layer<32, 4, 32, 4, false, false, SAVE>(wp + seg_off4(SEG_DIR), nullptr, lane, A, B, st0, nullptr, sv_rows(S_FEAT));
-  RSTAMP(3);  // point_info + dir_info (1,544 MFMAs = 98,816 cycles)
+  RSTAMP(6);  // point_info + dir_info (1,544 MFMAs = 98,816 cycles)
   // ---- colour head (VALU): rgb = sigmoid(W_c relu(.) + b)  (nerf.py:99, 119)
   {
     const float* wc = a.w.p[W_COLOR] + 4 * h;
@@ -281,9 +302,9 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
         const float4 q0 = *reinterpret_cast<const float4*>(wc + 32 * t + 8 * g);
         const float4 q1 = *reinterpret_cast<const float4*>(wc + HALF + 32 * t + 8 * g);
         const float4 q2 = *reinterpret_cast<const float4*>(wc + 2 * HALF + 32 * t + 8 * g);
-        const float c0 = fmaxf(B[t][4 * g + 0], 0.f), c1 = fmaxf(B[t][4 * g + 1], 0.f);
-        const float c2 = fmaxf(B[t][4 * g + 2], 0.f), c3 = fmaxf(B[t][4 * g + 3], 0.f);
-        if (SAVE && valid) *reinterpret_cast<float4*>(srow + S_C * MS + 32 * t + 8 * g) = make_float4(c0, c1, c2, c3);
+        const float c0 = relu1(B[t][4 * g + 0]), c1 = relu1(B[t][4 * g + 1]);
+        const float c2 = relu1(B[t][4 * g + 2]), c3 = relu1(B[t][4 * g + 3]);
+        if (SAVE) *reinterpret_cast<float4*>(srow + S_C * MS + 32 * t + 8 * g) = make_float4(c0, c1, c2, c3);
         z0 = __builtin_fmaf(c3, q0.w, __builtin_fmaf(c2, q0.z, __builtin_fmaf(c1, q0.y, __builtin_fmaf(c0, q0.x, z0))));
         z1 = __builtin_fmaf(c3, q1.w, __builtin_fmaf(c2, q1.z, __builtin_fmaf(c1, q1.y, __builtin_fmaf(c0, q1.x, z1))));
         z2 = __builtin_fmaf(c3, q2.w, __builtin_fmaf(c2, q2.z, __builtin_fmaf(c1, q2.y, __builtin_fmaf(c0, q2.x, z2))));
@@ -299,10 +320,10 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
     }
   }
 #ifdef NERF_STAMPS
-  RSTAMP(4);  // colour head + stores
+  RSTAMP(7);  // colour head + stores
   if (a.stamps && lane == 0) {
-    for (int i = 0; i < 5; ++i) atomicAdd(a.stamps + i, tsum[i]);
-    atomicAdd(a.stamps + 7, 1ull);
+    for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, tsum[i]);
+    atomicAdd(a.stamps + 31, 1ull);
   }
 #endif
 }

@@ -48,6 +48,7 @@ struct FieldArgs {
   int tile0;               // first tile of this pass in the mask buffer
   int tiles_tot;
   long long Mtot;
+  long long MSrows;        // rows per saved tensor = Mtot + DUMP_ROWS: lanes past the end of a pass store to their own dump row
   int N;                   // samples per ray
   int M;                   // samples of this pass (B*N)
   unsigned long long* stamps;  // diagnostic build (-DNERF_STAMPS) only: [8] cycle sums per phase
@@ -142,18 +143,32 @@ struct FieldBwdArgs {
   int wb0, wb_tot;
   int row0, tile0, tiles_tot;
   long long Mtot;
+  long long MSrows;        // rows per tensor of save / G = Mtot + DUMP_ROWS (see FieldArgs)
   int N, M;
+  unsigned long long* stamps;  // diagnostic build only: cycle sums per phase (workspace dbg words [32, 64))
 };
 
-struct DwProblem {
-  const float* G; int ldg; int nout;      // [Mtot][ldg]; nout = 256 or 128
-  const float* X; int ldx; int nin;       // [Mtot][ldx]; nin  = 256 or 64 (padded)
-  float* dW; int ldw; int col0; int nin_real;  // destination [nout][ldw], columns col0 .. col0 + nin_real
-  float* db;                              // [nout] bias gradient (column sums of G) or null
-  long long Mtot;
-  float* slabs;                           // scratch: nslabs * (nout*nin + nout) floats
+// One weight-gradient product dW = G^T X of the fp32 train step (dw_f32.hip).
+struct DwItem {
+  const float* G;          // [Mtot][256] pre-activation gradients, columns [0, nout)   (thin: the [Mtot][4] buffer dz_r, dz_g, dz_b, dsigma_pre)
+  const float* X;          // [Mtot][256] layer inputs, columns [0, nin)                 (thin: h7)
+  const float* X2;         // thin only: c (128 columns)
+  int nout, nin;           // 256 / 128 output columns, 256 / 64 (padded) input columns
+  int nin_real;            // input columns that exist in dW (60 of 64 for gamma_p)
+  float* dW; int ldw, col0;  // destination [nout][ldw], columns col0 .. col0 + nin_real      (thin: dW_color[3][128])
+  float* db;               // [nout] bias gradient = column sums of G, or null                 (thin: db_color[3])
+  float* dW2; float* db2;  // thin only: dw_sigma[256], db_sigma[1]
+  int thin;                // 1: the colour + sigma heads as one product
+  long long slab_off;      // floats: this product's slabs inside DwBatch::slabs
+  unsigned long long* stamps;  // diagnostic build only: per-wave (start, end, xcc, hw id) records
 };
 constexpr int DW_WGS = 256;  // one workgroup per CU
+constexpr int DW_MAX_ITEMS = 13;
+struct DwBatch {
+  DwItem item[DW_MAX_ITEMS];
+  int n;
+  const float* slabs;
+};
 
 struct MergeBwdArgs {
   const float* dC_f;       // [B][3]
@@ -184,6 +199,7 @@ struct SmallGradArgs {
   const float* dspre;      // [Mtot]
   const float* rayf;
   long long Mtot;
+  long long MSrows;        // rows per tensor of save / G (Mtot + DUMP_ROWS)
   int B, Nc, Nf;
   float *dW_color, *db_color, *dw_sigma, *db_sigma, *dW_dir;  // destinations (dW_dir: [128][280], cols 0..23 written)
   float* sbuf;             // [B][128] scratch: per-ray sums of dpre_dir
@@ -201,9 +217,9 @@ hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned c
                                 hipStream_t st);
 hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count,
                                  float* dW, int ldw, int col0, float* db, hipStream_t st);
-hipError_t launch_dw(const DwProblem& p, hipStream_t st);
-size_t dw_slab_floats(int nout, int nin);
-size_t dw_slab_floats_max();
+hipError_t launch_dw(const DwItem& p, long long Mtot, float* slabs, hipStream_t st);  // one product -> its slabs
+hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st);                         // all slabs of the step -> gradients
+size_t dw_item_slab_floats(const DwItem& p);
 hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st);
 size_t merge_bwd_lds_bytes(int N);
 hipError_t launch_merge_bwd(const MergeBwdArgs& a, hipStream_t st);

@@ -11,8 +11,10 @@ What can be asserted, and why (measurements in DESIGN.md section 6, all reproduc
 So: (1) every well-conditioned piece is held to 1e-4 (merge backward, resampling backward, the whole dX chain and
 weight-gradient GEMMs on a coarse-only loss, the colour / direction / feature branches of the full loss);
 (2) with the reference's discrete decisions replayed (sort order, ReLU masks) the full gradient must sit inside the
-reference's own fp32 noise band; (3) the untouched product path must give the loss to 1e-5, the well-conditioned
-gradients to 1e-3 and the rest inside the reference's sensitivity band.
+reference's own fp32 noise band; (3) the untouched product path must give the loss to 1e-5 and every gradient tensor
+within twice the reference's own shift under a 1e-6 relative weight perturbation, computed per case and per tensor in the test;
+(4) with the decisions replayed every tensor is compared with a float64 evaluation of the same branch: the device may not be
+further from it than 2.5x the reference's own fp32 gradient is (measured 0.8-1.8x).
 """
 import numpy as np
 import pytest
@@ -23,7 +25,6 @@ from conftest import golden_inputs, l2_rel, load_golden
 pytestmark = pytest.mark.gpu
 GTOL = 1e-4          # well-conditioned gradients
 NOISE_BAND = 2e-2    # full gradient with the reference's discrete decisions replayed (reference fp32-vs-fp64: ~1e-2)
-CHAOS_BAND = 0.3     # full gradient with the device's own decisions (reference under a 1e-6 perturbation: up to 0.14)
 
 
 def _relu_mask_image(hidden, tiles):
@@ -177,7 +178,7 @@ def test_resample_backward_stage(oracle, pkg, dev, name):
 # ---------------------------------------------------------------------------------------------------------------
 # (2) full gradient with the reference's decisions replayed: inside the reference's own fp32 noise band
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ["cfg2_lego_rand4096"])  # incl. once at cfg2's own size (4096 rays)
 def test_full_gradient_given_reference_decisions(oracle, pkg, dev, name):
     """Reference = the oracle's autograd run in THIS process (the golden gradients were produced on another host whose
     BLAS rounds differently, i.e. with other discrete decisions; they are compared in test_train_step_end_to_end)."""
@@ -221,31 +222,136 @@ def test_position_gradient_is_as_accurate_as_the_reference(oracle, pkg, dev):
     assert e_dev < max(1.5 * e_ref, 2e-3)
 
 
+def _fp64_grads_with_decisions(oracle, w, inputs, Nc, Nf, st):
+    """The branch of the reference's piecewise-smooth graph that its fp32 run took, evaluated in float64: every discrete
+    decision -- ReLU masks and the sign inside |.|, the resampling bin k, the five per-channel sort permutations -- comes from
+    the fp32 stages `st`.  Returns {name: gradient (float64)} of the reference's loss."""
+    import torch.nn.functional as F
+
+    row, col, pb, K, Ct = inputs
+    p = {k: v.double().clone().requires_grad_(True) for k, v in w.items()}
+    f_p32, _ = oracle.frequencies()
+    f_p = f_p32.double()
+    R, o, near, far = [x.double() for x in oracle.poses_extract(pb)]
+    d_cam = st["d_cam"].double()
+    gd32, gd = st["gd"], st["gd"].double()
+
+    def field(pts, pts32, n):
+        with torch.no_grad():
+            _, _, hid32, _, c32 = oracle.mlp(w, oracle.encode(pts32, f_p32), gd32[:, None, :].expand(-1, n, -1), return_hidden=True)
+            pre32 = F.linear(hid32[7], w["network.sigma_layer.0.weight"], w["network.sigma_layer.0.bias"]).squeeze(-1)
+        gp = oracle.encode(pts, f_p)
+        h = gp
+        for i in range(8):
+            inp = torch.cat((h, gp), dim=-1) if i == 4 else h
+            h = F.linear(inp, p[f"network.point_layer.{i}.0.weight"], p[f"network.point_layer.{i}.0.bias"]) * (hid32[i] > 0)
+        sigma = F.linear(h, p["network.sigma_layer.0.weight"], p["network.sigma_layer.0.bias"]).squeeze(-1) * torch.sign(pre32)
+        feat = F.linear(h, p["network.point_info.weight"], p["network.point_info.bias"])
+        c = F.linear(torch.cat((gd[:, None, :].expand(-1, n, -1), feat), dim=-1), p["network.dir_info.0.weight"],
+                     p["network.dir_info.0.bias"]) * (c32 > 0)
+        return torch.sigmoid(F.linear(c, p["network.color_layer.0.weight"], p["network.color_layer.0.bias"])), sigma
+
+    t_c = st["t_c"].double()
+    rgb_c, sig_c = field(oracle.sample_points(R, o, d_cam, t_c), st["pts_c"], Nc)
+    w_c = oracle.weights_from_sigma(((far - near) / Nc)[:, None].expand(-1, Nc), sig_c)
+    cdf = torch.cumsum(w_c, dim=1)
+    hi, lo = cdf[:, -1].detach(), cdf[:, 0].detach()  # max / min of a non-decreasing sequence
+    slope = torch.cat(((t_c[0, 1] - t_c[0, 0]) / (w_c[:, 1:] + 1e-7), torch.zeros(t_c.shape[0], 1, dtype=torch.float64)), dim=1)
+    u = torch.arange(1, Nf + 1, dtype=torch.float64)[None, :] * ((hi - lo) / (Nf + 1))[:, None] + lo[:, None]
+    k = st["k"]
+    t_f = torch.gather(t_c, 1, k) + (u - torch.gather(cdf, 1, k)) * torch.gather(slope, 1, k)
+    rgb_f, sig_f = field(oracle.sample_points(R, o, d_cam, t_f), st["pts_f"], Nf)
+    bundle = torch.cat((torch.cat((t_c, t_f), 1).unsqueeze(2), torch.cat((rgb_c, rgb_f), 1), torch.cat((sig_c, sig_f), 1).unsqueeze(2)), dim=2)
+    sb = torch.gather(bundle, 1, st["perm"])
+    t_s, rgb_s, sig_s = sb[:, :, 0], sb[:, :, 1:4], sb[:, :, 4]
+    delta = torch.cat((t_s[:, 1:] - t_s[:, :-1], torch.full((t_s.shape[0], 1), 1e-4, dtype=torch.float64)), dim=1)
+    C_c, C_f = oracle.composite(w_c, rgb_c), oracle.composite(oracle.weights_from_sigma(delta, sig_s), rgb_s)
+    oracle.ray_loss(C_c, C_f, Ct.double()).backward()
+    return {k_: v.grad for k_, v in p.items()}
+
+
+@pytest.mark.parametrize("name", ["cfg1_lego_crop32", "cfg1_lego_crop32_sharp", "cfg4_fern_rand512"])
+def test_every_gradient_is_as_accurate_as_the_reference(oracle, pkg, dev, name):
+    """All 24 tensors, full loss, the reference's decisions replayed: the device gradient must not be further from the
+    float64 evaluation of the same branch than 2.5x what the reference's own fp32 gradient is (floor 1e-4; measured: the
+    device sits at 0.8-1.8x -- its dot products are strict k-ordered fma chains, the host BLAS sums in blocks).  This is the
+    statement a flat tolerance cannot make: where the fp32 reference itself is 1 % away from fp64, so may the device be;
+    where it is 1e-6 away, the device is held to 1e-4."""
+    g, inputs, Nc, Nf, w = _case(oracle, name, max_rays=256)
+    p, st, _ = _oracle_with_grads(oracle, w, inputs, Nc, Nf)
+    std = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st.items()}
+    truth = _fp64_grads_with_decisions(oracle, w, inputs, Nc, Nf, std)
+    m, _ = _train_step(pkg, oracle, dev, w, inputs, Nc, Nf, ref_stages=std)
+    rows = []
+    for (k, ref), q in zip(p.items(), m.network.parameters()):
+        e_ref, e_dev = l2_rel(ref.grad, truth[k]), l2_rel(q.grad, truth[k])
+        rows.append((k, e_ref, e_dev))
+    for k, e_ref, e_dev in rows:
+        print(f"  {k:40s} reference fp32 vs fp64 {e_ref:.2e}   device vs fp64 {e_dev:.2e}")
+    for k, e_ref, e_dev in rows:
+        assert e_dev < max(2.5 * e_ref, 1e-4), (k, e_ref, e_dev)
+    worst = max(rows, key=lambda r: r[2] / max(r[1], 1e-30))
+    print(f"{name}: vs fp64 -- reference fp32 {min(r[1] for r in rows):.1e}..{max(r[1] for r in rows):.1e}, device "
+          f"{min(r[2] for r in rows):.1e}..{max(r[2] for r in rows):.1e}; largest device/reference ratio {worst[2] / max(worst[1], 1e-30):.2f} ({worst[0]})")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # (3) the untouched product path
 # ---------------------------------------------------------------------------------------------------------------
+def _oracle_grads(oracle, w, inputs, Nc, Nf):
+    row, col, pb, K, Ct = inputs
+    _, _, loss, g = oracle.loss_and_grads(w, row, col, pb, K, Ct, Nc, Nf)
+    return loss, g
+
+
+def _sensitivity_band(oracle, w, inputs, Nc, Nf, g0, seeds, rel=1e-6):
+    """The reference's OWN gradient shift when its weights move by a seeded relative 1e-6 -- the size of the difference
+    between two correct fp32 evaluations of the MLP (GEMM summation order: 1.3e-6 on C_coarse).
+    Per tensor, L2-rel, maximum over the seeds."""
+    band = {k: 0.0 for k in g0}
+    for sd in seeds:
+        gen = torch.Generator().manual_seed(sd)
+        wp = {k: v * (1.0 + rel * torch.randn(v.shape, generator=gen)) for k, v in w.items()}
+        _, g1 = _oracle_grads(oracle, wp, inputs, Nc, Nf)
+        for k in g0:
+            band[k] = max(band[k], l2_rel(g1[k], g0[k]))
+    return band
+
+
 @pytest.mark.parametrize("name", CASES + ["cfg2_lego_rand4096"])
 def test_train_step_end_to_end(oracle, pkg, dev, name):
+    """The untouched product path against the oracle's autograd run in THIS process.  The reference's gradient is discontinuous
+    in its own MLP outputs (module docstring), so the bar is not a flat number: per case and per tensor it is twice the
+    reference's own gradient shift under a seeded 1e-6 relative weight perturbation (floor 1e-3), and the loss itself 1e-5.
+    The golden gradients (another host's BLAS = other discrete decisions) are held to the same band."""
     g = load_golden(name)
     inputs = golden_inputs(g)
+    Nc, Nf = int(g["Nc"]), int(g["Nf"])
     w = oracle.make_weights(int(g["seed"]), bool(g["sharp"]))
-    m, loss = _train_step(pkg, oracle, dev, w, inputs, int(g["Nc"]), int(g["Nf"]))
-    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
-    worst = 0.0
+    m, loss = _train_step(pkg, oracle, dev, w, inputs, Nc, Nf)
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    _, g0 = _oracle_grads(oracle, w, inputs, Nc, Nf)
+    band = _sensitivity_band(oracle, w, inputs, Nc, Nf, g0, seeds=(1,) if name.startswith("cfg2") else (1, 2))
+    worst = (0.0, 0.0, "")
     for k, q in m.named_parameters():
+        key = "network." + k if not k.startswith("network.") else k
         got = q.grad.detach().cpu().double()
-        assert torch.isfinite(got).all()
-        gn = float(g["gnorm_" + k])
-        assert abs(float(got.norm()) - gn) <= 0.1 * gn, (k, float(got.norm()), gn)
-        if "grad_" + k in g:
-            ref = torch.from_numpy(g["grad_" + k]).double()
-            e = float((got - ref).norm() / ref.norm())
+        assert torch.isfinite(got).all(), k
+        e = l2_rel(got, g0[key])
+        bar = max(2.0 * band[key], 1e-3)
+        if e / bar > worst[0] / max(worst[1], 1e-30):
+            worst = (e, bar, k)
+        assert e < bar, (k, e, band[key])
+        # the golden file's gradients of this tensor (full, or every 97th element), produced on another host
+        gn = float(g["gnorm_" + key])
+        assert abs(float(got.norm()) - gn) <= max(2.0 * band[key], 1e-3) * gn + 1e-12, (k, float(got.norm()), gn)
+        if "grad_" + key in g:
+            e2 = l2_rel(got, torch.from_numpy(g["grad_" + key]))
         else:
-            ref = torch.from_numpy(g["gslice_" + k]).double()
-            e = float((got.flatten()[::97] - ref).norm() / max(float(ref.norm()), 1e-30))
-        worst = max(worst, e)
-        assert e < (1e-3 if "color_layer" in k else CHAOS_BAND), (k, e)
-    print(f"{name}: worst grad L2-rel (own decisions) {worst:.2e}")
+            ref = torch.from_numpy(g["gslice_" + key]).double()
+            e2 = float((got.flatten()[::97] - ref).norm() / max(float(ref.norm()), 1e-30))
+        assert e2 < max(3.0 * band[key], 2e-3), (k, e2, band[key])
+    print(f"{name}: closest to its bar: {worst[2]} L2-rel {worst[0]:.2e} (bar {worst[1]:.2e} = 2 x the reference's own 1e-6 sensitivity)")
 
 
 def test_odd_sizes_coarse_only(oracle, pkg, dev):

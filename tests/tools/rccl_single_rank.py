@@ -36,6 +36,9 @@ def main():
         m.load_state_dict(w)
         return m.to(dev)
 
+    def same(a, b):  # summation order of the slab / atomic reductions may differ between two runs: equal to 1e-5, not bitwise
+        return float((a.double() - b.double()).norm()) <= 1e-5 * float(b.double().norm()) + 1e-30
+
     # (a) plain autograd path, no bucket
     m = model(B)
     Cc, Cf = m(row, col, pbd, K)
@@ -49,7 +52,7 @@ def main():
     torch.cuda.synchronize()
     for p, v, r in zip(m1.network.parameters(), bucket.views, ref):
         assert p.grad.data_ptr() == v.data_ptr(), "p.grad must alias the flat all-reduce buffer"
-        assert torch.equal(p.grad, r), "bucketed gradient differs from the plain autograd gradient"
+        assert same(p.grad, r), "bucketed gradient differs from the plain autograd gradient"
     used = torch.zeros_like(bucket.flat, dtype=torch.bool)
     for v in bucket.views:
         used[(v.data_ptr() - bucket.flat.data_ptr()) // 4:][: v.numel()] = True
@@ -59,7 +62,7 @@ def main():
     # a second step overwrites (does not accumulate) -- the C ABI's semantics, like zero_grad() + backward()
     par.train_step_sharded(m1, bucket, row, col, pbd, K, Ctd, rank=0, world=1)
     for p, r in zip(m1.network.parameters(), ref):
-        assert torch.equal(p.grad, r)
+        assert same(p.grad, r)
 
     # (c) two shards of the same batch, each through train_step_sharded (the all-reduce of this 1-rank group is the identity):
     # their flat buffers add up to the full-batch gradient (loss = SUM over rays, global ray 0 handed to both)
