@@ -54,37 +54,46 @@ size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 
 // The twelve weight-gradient products of the fp32 train step (dw_f32.hip) with their slab offsets; pointers are filled in
 // by nerf_hip_backward (null here: only sizes matter for the layout).
-int build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw) {
+long long build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw) {
   memset(&b, 0, sizeof(b));
-  long long off = 0;
-  auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db) -> DwItem& {
+  // MFMA time of each product in units of a 256 x 256 one (the thin-heads product is load-bound: measured 0.35)
+  float units[DW_MAX_ITEMS];
+  auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db, float u) -> DwItem& {
+    units[b.n] = u;
     DwItem& it = b.item[b.n++];
     it.G = g; it.X = x; it.nout = nout; it.nin = nin; it.nin_real = nin_real; it.dW = dW; it.ldw = ldw; it.col0 = col0; it.db = db;
-    it.slab_off = off;
-    off += (long long)dw_item_slab_floats(it);
     return it;
   };
   auto Gt = [&](int t) { return G ? G + (size_t)t * MS : nullptr; };
   auto St = [&](int t) { return save ? save + (size_t)t * MS : nullptr; };
   auto D = [&](int i) { return dw ? dw[i] : nullptr; };
-  add(Gt(0), 256, St(S_GP), 64, POINT_DIM, D(0), POINT_DIM, 0, D(1));                          // layer 0: X = gamma_p
-  for (int l = 1; l <= 7; ++l)                                                                   // layers 1..7 (layer 4: hidden columns)
-    add(Gt(l), 256, St(l - 1), 256, 256, D(2 * l), l == 4 ? WIDTH + POINT_DIM : WIDTH, 0, D(2 * l + 1));
-  add(Gt(4), 256, St(S_GP), 64, POINT_DIM, D(8), WIDTH + POINT_DIM, WIDTH, nullptr);            // layer 4, skip columns
-  add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI));                              // point_info
-  add(Gt(G_D), 128, St(S_FEAT), 256, 256, D(W_DIR), WIDTH + DIR_DIM, DIR_DIM, D(B_DIR));        // dir_info, feature columns
-  DwItem& th = add(dz4, 32, St(7), 384, 384, D(W_COLOR), HALF, 0, D(B_COLOR));                  // colour + sigma heads: X = [h7 | c]
+  add(Gt(0), 256, St(S_GP), 64, POINT_DIM, D(0), POINT_DIM, 0, D(1), 0.25f);                          // layer 0: X = gamma_p
+  for (int l = 1; l <= 7; ++l)                                                                          // layers 1..7 (layer 4: hidden columns)
+    add(Gt(l), 256, St(l - 1), 256, 256, D(2 * l), l == 4 ? WIDTH + POINT_DIM : WIDTH, 0, D(2 * l + 1), 1.0f);
+  add(Gt(4), 256, St(S_GP), 64, POINT_DIM, D(8), WIDTH + POINT_DIM, WIDTH, nullptr, 0.25f);            // layer 4, skip columns
+  add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI), 1.0f);                               // point_info
+  add(Gt(G_D), 128, St(S_FEAT), 256, 256, D(W_DIR), WIDTH + DIR_DIM, DIR_DIM, D(B_DIR), 0.5f);         // dir_info, feature columns
+  DwItem& th = add(dz4, 32, St(7), 384, 384, D(W_COLOR), HALF, 0, D(B_COLOR), 0.35f);                  // colour + sigma heads: X = [h7 | c]
   th.thin = 1; th.X2 = St(S_C); th.dW2 = D(W_SIGMA); th.db2 = D(B_SIGMA);
-  // (thin was flagged after add(): its slab size is smaller than add() assumed -- harmless, it is the last item)
-  return b.n;
+  // Every product gets ALL DW_WGS workgroups in a launch of its own.  (One launch for all products, the CUs dealt out in
+  // proportion to `units`, was built and measured: 22 ms instead of 7.7 -- twelve products streaming 24 operand tensors
+  // concurrently, each workgroup over a 28,000-row range, is not what the memory system likes; workgroup barriers that
+  // keep the waves on the same rows did not help.  See DESIGN.md section 4.)
+  (void)units;
+  for (int i = 0; i < b.n; ++i) b.item[i].nwg = DW_WGS;
+  long long off = 0;
+  int wg0 = 0;
+  (void)wg0;
+  for (int i = 0; i < b.n; ++i) {
+    b.item[i].wg0 = 0;
+    b.item[i].slab_off = off; off += (long long)dw_item_slab_floats(b.item[i]);
+  }
+  return off;  // slab floats of the whole batch
 }
 
 size_t dw_batch_slab_floats() {
   DwBatch b;
-  build_dw_batch(b, nullptr, nullptr, nullptr, 0, nullptr);
-  const DwItem& last = b.item[b.n - 1];
-  DwItem full = last; full.thin = 0; full.nout = 256; full.nin = 256;  // upper bound for the last item
-  return (size_t)last.slab_off + dw_item_slab_floats(full);
+  return (size_t)build_dw_batch(b, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
 WsLayout layout(int B, int Nc, int Nf, int flags) {
@@ -470,12 +479,10 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     build_dw_batch(batch, G, save, at<float>(ws, L.dz), MS, dw);
     float* slabs = at<float>(ws, L.slabs);
     batch.slabs = slabs;
-    for (int i = 0; i < batch.n; ++i) {
 #ifdef NERF_STAMPS
-      batch.item[i].stamps = at<unsigned long long>(ws, L.dbg) + 64;
+    batch.item[1].stamps = at<unsigned long long>(ws, L.dbg) + 64;  // layer 1: a 256 x 256 product
 #endif
-      HIP_TRY(launch_dw(batch.item[i], Mtot, slabs, st));
-    }
+    HIP_TRY(launch_dw(batch, Mtot, slabs, st));
     HIP_TRY(launch_dw_reduce(batch, st));
     // direction-encoding columns of dir_info (per-ray sums)
     SmallGradArgs sg;

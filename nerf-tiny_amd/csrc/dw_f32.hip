@@ -1,13 +1,12 @@
 // dw_f32.hip -- the weight-gradient GEMMs of the fp32 train step for MI355X (gfx950).
 //
-//  k_dw<NCA>      dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32 with the
+//  k_dw           one launch for every product; per product (dw_item<NCA>): dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32 with the
 //                 SAMPLE as the k index): both operands are read straight from their row-major HBM images (lane (q, h) <-
 //                 columns 4q..4q+3 of G and 2q..2q+1 of X, row m + h), one 128 x 64 output block = 128 accumulators per
 //                 wave, 8 waves (two per SIMD), one workgroup per CU, a branch-free 3-stage register rotation with pinned
 //                 prefetches, per-wave partial slabs.  fp32 MFMA runs on the SIMD's fp32 lanes, so every VALU instruction
-//                 in the loop is MFMA time lost: addresses are SCALAR (wave-uniform row cursor in SGPRs + one constant
-//                 32-bit lane offset; the loop has no vector address arithmetic), and the bias gradients (column sums of
-//                 G, four adds per k-step) ride on one of the waves that read the same G columns.
+//                 in the loop is MFMA time lost; the bias gradients (column sums of G, four adds per k-step) ride on one of
+//                 the waves that read the same G columns.
 //                 NCA = 1: the thin heads as one product -- A = the [rows][4] buffer (dz_r, dz_g, dz_b, dsigma_pre), one
 //                 32-row output tile per wave, X = [h7 | c]: rows 0..2 x c give the colour head, row 3 x h7 the sigma head,
 //                 the column sums of A their biases.
@@ -36,85 +35,39 @@ struct DwStage {
   float2 b[DW_UNROLL];
 };
 
-// 16-byte / 8-byte loads in the SADDR form `scalar 64-bit base + 32-bit lane offset + immediate`: no vector address
-// arithmetic.  Written as inline asm because the compiler re-associates base + row cursor + lane offset into per-lane
-// 64-bit pointers and then advances those with vector adds every stage.  The compiler does not see these as memory
-// operations, so the loop below counts its own `s_waitcnt vmcnt` (always 16: two younger stages of 8 loads) and threads the
-// loaded registers through the wait so that no use can be scheduled above it.
-typedef float f32x4 __attribute__((ext_vector_type(4)));  // register tuples for asm operands (HIP's float4 is a struct)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int IMM>
-__device__ __forceinline__ float4 gload_x4(unsigned voff, const char* sbase) {
-  f32x4 d;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
-  return make_float4(d[0], d[1], d[2], d[3]);
-}
-template <int IMM>
-__device__ __forceinline__ float2 gload_x2(unsigned voff, const char* sbase) {
-  f32x2 d;
-  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
-  return make_float2(d[0], d[1]);
-}
-
-// Main loop over rows [r_begin, r_end) (wave-uniform).  CHECK = false: every row of every stage is in range; with ASM_LOADS
-// the row cursor, its clamp and the bases are scalar-ALU work and the loop holds no vector instruction but MFMAs (and, BIAS,
-// the four column-sum adds per k-step).  CHECK = true (the ragged tail of a pass only): rows are clamped per lane and rows
-// past the end contribute nothing.  Rows are 32-bit (a pass has < 2^31 rows and < 4 GiB per operand).
-template <int NCA, bool CHECK, bool BIAS>
-__device__ __forceinline__ void dw_rows(const char* __restrict__ gbase, const char* __restrict__ xbase, unsigned ga_row_bytes,
-                                        unsigned voff_a, unsigned voff_b, int r_begin, int r_end, int h, bool a_live,
-                                        f32x16 (&acc)[NCA][2], float (&bsum)[4]) {
-#ifdef DW_NO_ASM_LOADS  // A/B switch: plain loads (the compiler then advances per-lane 64-bit pointers with vector adds)
-  constexpr bool ASM_LOADS = false;
-#else
-  constexpr bool ASM_LOADS = (NCA == 4) && !CHECK;
-#endif
-  auto load = [&](int r0, DwStage<NCA>& S) {
-    if (ASM_LOADS) {
-      const char* g0 = gbase + (size_t)((unsigned)r0 * (unsigned)(WIDTH * 4));  // rows r0 + {0, 2}: immediates 0 / 2048 (+ row h in voff)
-      const char* g1 = g0 + 4 * (WIDTH * 4);                                     // rows r0 + {4, 6}
-      const char* x0 = xbase + (size_t)((unsigned)r0 * (unsigned)(WIDTH * 4));
-      const char* x1 = x0 + 4 * (WIDTH * 4);
-      S.a[0] = gload_x4<0>(voff_a, g0);
-      S.a[1] = gload_x4<2 * WIDTH * 4>(voff_a, g0);
-      S.a[2] = gload_x4<0>(voff_a, g1);
-      S.a[3] = gload_x4<2 * WIDTH * 4>(voff_a, g1);
-      S.b[0] = gload_x2<0>(voff_b, x0);
-      S.b[1] = gload_x2<2 * WIDTH * 4>(voff_b, x0);
-      S.b[2] = gload_x2<0>(voff_b, x1);
-      S.b[3] = gload_x2<2 * WIDTH * 4>(voff_b, x1);
+// Main loop over rows [r_begin, r_end) (wave-uniform).  CHECK = false: every row of every stage is in range (no selects
+// between the loads and their use, so the loads of two stages stay in flight behind the MFMAs of the third).  CHECK = true
+// (the ragged tail of a pass only): rows are clamped per lane and rows past the end contribute nothing.
+// gp / xp: this lane's operand pointers at row 0 (column group q; row h is added per stage).
+// (Scalar-base loads -- `global_load v, v_off32, s[base:base+1]`, no vector address arithmetic at all -- were built as inline
+// asm and measured 2 % faster, but an asm load's destination is invisible to the register allocator: it placed copies of
+// in-flight stage registers in front of the waits on some code paths, i.e. stale operands.  Plain loads it is.)
+template <int NCA, bool CHECK>
+__device__ __forceinline__ void dw_rows(const bool BARRIER, const bool BIAS, const float* __restrict__ gp, const float* __restrict__ xp, int ga_row_floats, long long r_begin,
+                                        long long r_end, int h, bool a_live, f32x16 (&acc)[NCA][2], float (&bsum)[4]) {
+  auto load = [&](long long r0, DwStage<NCA>& S) {
+    if (!CHECK) {
+      // one 64-bit offset per stage and operand; the four row pairs are immediates of it
+      const float* ga = gp + (size_t)(r0 + h) * ga_row_floats;
+      const float* xb = xp + (size_t)(r0 + h) * WIDTH;
+#pragma unroll
+      for (int u = 0; u < DW_UNROLL; ++u) {
+        if (NCA == 4) S.a[u] = *reinterpret_cast<const float4*>(ga + (size_t)u * 2 * WIDTH);
+        else S.a[u].x = ga[u * 2 * 4];
+        S.b[u] = *reinterpret_cast<const float2*>(xb + (size_t)u * 2 * WIDTH);
+      }
       return;
     }
 #pragma unroll
     for (int u = 0; u < DW_UNROLL; ++u) {
-      int r = r0 + 2 * u + h;
-      if (CHECK) r = r < r_end ? r : r_end - 1;
-      const char* ga = gbase + (size_t)((unsigned)r * ga_row_bytes) + (voff_a - (unsigned)h * ga_row_bytes);
-      const char* xb = xbase + (size_t)((unsigned)r * (unsigned)(WIDTH * 4)) + (voff_b - (unsigned)h * (WIDTH * 4));
-      if (NCA == 4) S.a[u] = *reinterpret_cast<const float4*>(ga);
-      else S.a[u].x = *reinterpret_cast<const float*>(ga);
-      S.b[u] = *reinterpret_cast<const float2*>(xb);
+      long long r = r0 + 2 * u + h;
+      r = r < r_end ? r : r_end - 1;
+      if (NCA == 4) S.a[u] = *reinterpret_cast<const float4*>(gp + (size_t)r * ga_row_floats);
+      else S.a[u].x = gp[(size_t)r * ga_row_floats];
+      S.b[u] = *reinterpret_cast<const float2*>(xp + (size_t)r * WIDTH);
     }
   };
-  // ASM_LOADS: wait until this stage has landed (the two younger stages = 16 loads may still be in flight)
-  auto landed = [&](DwStage<NCA>& S) {
-    if (ASM_LOADS) {
-      f32x4 a[4];
-      f32x2 b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a[u] = f32x4{S.a[u].x, S.a[u].y, S.a[u].z, S.a[u].w};
-        b[u] = f32x2{S.b[u].x, S.b[u].y};
-      }
-      asm volatile("s_waitcnt vmcnt(16)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory");
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        S.a[u] = make_float4(a[u][0], a[u][1], a[u][2], a[u][3]);
-        S.b[u] = make_float2(b[u][0], b[u][1]);
-      }
-    }
-  };
-  auto mul_u = [&](int r0, const DwStage<NCA>& S, int u) {
+  auto mul_u = [&](long long r0, const DwStage<NCA>& S, int u) {
     float4 a = S.a[u];
     if (NCA == 1) a.x = a_live ? a.x : 0.f;  // thin heads: lanes q >= 4 supply zero rows
     if (CHECK) {
@@ -129,67 +82,120 @@ __device__ __forceinline__ void dw_rows(const char* __restrict__ gbase, const ch
       if (NCA == 4) { bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w; }
     }
   };
-  auto mul = [&](int r0, const DwStage<NCA>& S) {
+  auto mul = [&](long long r0, const DwStage<NCA>& S) {
 #pragma unroll
     for (int u = 0; u < DW_UNROLL; ++u) mul_u(r0, S, u);
   };
-  constexpr int G = DW_ROWS;
+  constexpr long long G = DW_ROWS;
+  if (CHECK) {  // ragged tail of a pass: one stage at a time, no pipelining (a few waves of one launch take this path)
+    DwStage<NCA> s;
+    for (long long r0 = r_begin; r0 < r_end; r0 += G) {
+      load(r0, s);
+      mul(r0, s);
+    }
+    return;
+  }
   DwStage<NCA> s0, s1, s2;
   // branch-free rotation: the two prefetches past the end re-read the last stage (valid memory, never multiplied)
-  const int r_last = CHECK ? r_end : r_end - G;
-  auto at = [&](int r) { return (CHECK || r <= r_last) ? r : r_last; };
-  // ASM_LOADS: the two stages that stay in flight across the loop's back edge must have LANDED there -- the compiler is free to
-  // copy a loop-carried register at the edge (it did: v_mov of a stage whose loads were still in flight = stale operands on
-  // some rounds), and an asm load's destination counts as written at the statement.  So every round (3 stages, 96 MFMAs)
-  // ends with one full wait; inside the round the waits stay counted, two stages ahead.
-  auto landed_all = [&](DwStage<NCA>& A, DwStage<NCA>& B) {
-    if (ASM_LOADS) {
-      f32x4 a[8];
-      f32x2 b[8];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a[u] = f32x4{A.a[u].x, A.a[u].y, A.a[u].z, A.a[u].w};
-        b[u] = f32x2{A.b[u].x, A.b[u].y};
-        a[4 + u] = f32x4{B.a[u].x, B.a[u].y, B.a[u].z, B.a[u].w};
-        b[4 + u] = f32x2{B.b[u].x, B.b[u].y};
-      }
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]),
-                     "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
-                   :
-                   : "memory");
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        A.a[u] = make_float4(a[u][0], a[u][1], a[u][2], a[u][3]);
-        A.b[u] = make_float2(b[u][0], b[u][1]);
-        B.a[u] = make_float4(a[4 + u][0], a[4 + u][1], a[4 + u][2], a[4 + u][3]);
-        B.b[u] = make_float2(b[4 + u][0], b[4 + u][1]);
-      }
-    }
-  };
+  const long long r_last = r_end - G;
+  auto at = [&](long long r) { return r <= r_last ? r : r_last; };
   load(r_begin, s0);
   load(at(r_begin + G), s1);
-  landed_all(s0, s1);
-  for (int r0 = r_begin; r0 < r_end; r0 += 3 * G) {
+  unsigned round = 0;
+  for (long long r0 = r_begin; r0 < r_end; r0 += 3 * G) {
+    // Keep the workgroup's waves on the same rows: the 4 (or 2) waves that share an operand block read it from L1/L2 only
+    // while they stay within a few rounds of each other.  Unfenced, the older wave of every SIMD pair wins each MFMA
+    // arbitration and runs ahead (measured: it finishes at 78 % of the kernel's time); over a 28,000-row range that drift
+    // is megabytes, every wave then streams its operands from HBM on its own, and the phase becomes HBM-bound (3x slower).
+    // Every wave of a workgroup that gets here runs the same number of rounds (BARRIER is workgroup-uniform).
+    if (BARRIER && (round++ & 1) == 0) __builtin_amdgcn_s_barrier();
     // the scheduling barriers keep each stage's requests where they are written: two stages (64 MFMAs) ahead of
     // their use -- left alone the compiler sinks them next to the uses and every iteration waits on HBM
     load(at(r0 + 2 * G), s2);
     __builtin_amdgcn_sched_barrier(0);
-    mul(r0, s0);  // landed at the previous round's end
+    mul(r0, s0);
     __builtin_amdgcn_sched_barrier(0);
     load(at(r0 + 3 * G), s0);
     __builtin_amdgcn_sched_barrier(0);
-    mul(r0 + G, s1);  // landed at the previous round's end
+    mul(r0 + G, s1);
     __builtin_amdgcn_sched_barrier(0);
     load(at(r0 + 4 * G), s1);
     __builtin_amdgcn_sched_barrier(0);
-    landed(s2);  // younger: the 16 loads of s0, s1
     mul(r0 + 2 * G, s2);
-    __builtin_amdgcn_sched_barrier(0);
-    landed_all(s0, s1);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+// The 128 x 64 blocks of the big products run round 1's loop as it stands (same source, same register allocation): this
+// compiler's scheduling of the stage loads is brittle -- three rewrites of this loop (compile-time bias flag, one address per
+// stage, 32-bit row cursor) each compiled into a loop that waits for a stage right after requesting it, 1.5x slower.
+struct DwStage4 {
+  float4 a[DW_UNROLL];
+  float2 b[DW_UNROLL];
+};
+
+// main loop of k_dw over rows [r_begin, r_end).  CHECK = false: every row of every stage is in range (no selects
+// between the loads and their use, so the loads of two stages stay in flight behind the MFMAs of the third).
+template <bool CHECK>
+__device__ __forceinline__ void dw_rows4(const float* __restrict__ gp, const float* __restrict__ xp, long long r_begin,
+                                        long long r_end, int h, bool do_bias, f32x16 (&acc)[4][2], float (&bsum)[4]) {
+  auto load = [&](long long r0, DwStage4& S) {
+#pragma unroll
+    for (int u = 0; u < DW_UNROLL; ++u) {
+      // both operands have row stride WIDTH floats (all buffers of the workspace do)
+      if (CHECK) {
+        long long r = r0 + 2 * u + h;
+        r = r < r_end ? r : r_end - 1;
+        S.a[u] = *reinterpret_cast<const float4*>(gp + (size_t)r * WIDTH);
+        S.b[u] = *reinterpret_cast<const float2*>(xp + (size_t)r * WIDTH);
+      } else {
+        const size_t off = (size_t)(r0 + h) * WIDTH + (size_t)u * 2 * WIDTH;
+        S.a[u] = *reinterpret_cast<const float4*>(gp + off);
+        S.b[u] = *reinterpret_cast<const float2*>(xp + off);
+      }
+    }
+  };
+  auto mul = [&](long long r0, const DwStage4& S) {
+#pragma unroll
+    for (int u = 0; u < DW_UNROLL; ++u) {
+      float4 a = S.a[u];
+      if (CHECK) {
+        if (r0 + 2 * u + h >= r_end) a = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the end contribute nothing
+      }
+#pragma unroll
+      for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(S.b[u], cb), acc[ca][cb], 0, 0, 0);
+      if (do_bias) {
+        bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w;
+      }
+    }
+  };
+  constexpr long long G = 2 * DW_UNROLL;  // rows per stage
+  DwStage4 s0, s1, s2;
+  // branch-free rotation: the two prefetches past the end re-read the last stage (valid memory, never multiplied)
+  const long long r_last = CHECK ? r_end : r_end - G;
+  auto at = [&](long long r) { return (CHECK || r <= r_last) ? r : r_last; };
+  load(r_begin, s0);
+  load(at(r_begin + G), s1);
+  for (long long r0 = r_begin; r0 < r_end; r0 += 3 * G) {
+    // the scheduling barriers keep each stage's requests where they are written: two stages (64 MFMAs) ahead of
+    // their use -- left alone the compiler sinks them next to the uses and every iteration waits on HBM
+    load(at(r0 + 2 * G), s2);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(r0, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(at(r0 + 3 * G), s0);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(r0 + G, s1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(at(r0 + 4 * G), s1);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(r0 + 2 * G, s2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 
 }  // namespace
 
@@ -201,8 +207,13 @@ __host__ __device__ inline size_t dwi_wave_floats(const DwItem& p) { return (siz
 // per workgroup: 8 wave blocks + 8 x 128 column sums
 __host__ __device__ inline size_t dwi_wg_floats(const DwItem& p) { return DW_WAVES * (dwi_wave_floats(p) + 128); }
 
+// One workgroup's share of one product: rows [lw, lw + 1) * per_wg of its `nwg` workgroups (lw = workgroup index inside the
+// product).
+template <int N>
+__device__ __forceinline__ f32x16 (&acc4(f32x16 (&a)[N][2]))[4][2] { return reinterpret_cast<f32x16 (&)[4][2]>(a); }
+
 template <int NCA>
-__global__ __launch_bounds__(512, 2) void k_dw(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
+__device__ __forceinline__ void dw_item(const DwItem& p, const int lw, const long long Mtot, float* __restrict__ slabs) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform values stay in SGPRs from here on
 #ifdef NERF_STAMPS
@@ -216,9 +227,9 @@ __global__ __launch_bounds__(512, 2) void k_dw(const DwItem p, const long long M
   const int oA = NCA == 1 ? 0 : (blk / in_blocks) * 128;
   const int gran = DW_ROWS * DW_STAGES * msubs;
   const int Mrows = (int)Mtot;  // < 2^31 rows and < 4 GiB per operand (checked by the host)
-  const int per_wg = ((Mrows + DW_WGS - 1) / DW_WGS + gran - 1) / gran * gran;
+  const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran;
   const int per_wave = per_wg / msubs;  // a multiple of the 24 rows of one pipeline round
-  const long long r_begin64 = (long long)blockIdx.x * per_wg + (long long)msub * per_wave;
+  const long long r_begin64 = (long long)lw * per_wg + (long long)msub * per_wave;
   const int r_begin = r_begin64 < Mrows ? (int)r_begin64 : Mrows;
   const long long r_nom = r_begin64 + per_wave;
   const int r_end = r_nom > Mrows ? Mrows : (int)r_nom;
@@ -233,37 +244,42 @@ __global__ __launch_bounds__(512, 2) void k_dw(const DwItem p, const long long M
       for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-  // operand bases (uniform) and the one per-lane offset of each operand
-  const char* gbase;
-  const char* xbase;
-  unsigned ga_row_bytes, voff_a;
+  // this lane's operand pointers at row 0
+  const float* gp;
+  const float* xp;
+  int ga_row_floats;
   bool do_bias;  // wave-uniform: column sums of A on this wave
   if (NCA == 4) {
-    gbase = reinterpret_cast<const char*>(p.G + oA);
-    xbase = reinterpret_cast<const char*>(p.X + (blk % in_blocks) * 64);
-    ga_row_bytes = WIDTH * 4;
-    voff_a = (unsigned)h * (WIDTH * 4) + (unsigned)q * 16;
+    gp = p.G + oA + 4 * q;
+    xp = p.X + (blk % in_blocks) * 64 + 2 * q;
+    ga_row_floats = WIDTH;
     // column sums of G = bias gradient: one of the in_blocks waves that read the same G columns does them (4 adds per k-step;
     // two such waves per workgroup, on different SIMDs)
     do_bias = p.db != nullptr && (blk % in_blocks) == 0;
   } else {
-    gbase = reinterpret_cast<const char*>(p.G);  // [rows][4]
-    xbase = reinterpret_cast<const char*>(blk < 4 ? p.X + blk * 64 : p.X2 + (blk - 4) * 64);
-    ga_row_bytes = 16;
-    voff_a = (unsigned)h * 16 + (unsigned)(q & 3) * 4;
+    gp = p.G + (q & 3);  // [rows][4]
+    xp = (blk < 4 ? p.X + blk * 64 : p.X2 + (blk - 4) * 64) + 2 * q;
+    ga_row_floats = 4;
     do_bias = blk == 0;
   }
-  const unsigned voff_b = (unsigned)h * (WIDTH * 4) + (unsigned)q * 8;
   const bool a_live = q < 4;
-  if (r_begin < r_end) {
-    const bool full = r_nom <= Mrows;
-    if (full && do_bias) dw_rows<NCA, false, true>(gbase, xbase, ga_row_bytes, voff_a, voff_b, r_begin, r_end, h, a_live, acc, bsum);
-    else if (full) dw_rows<NCA, false, false>(gbase, xbase, ga_row_bytes, voff_a, voff_b, r_begin, r_end, h, a_live, acc, bsum);
-    else if (do_bias) dw_rows<NCA, true, true>(gbase, xbase, ga_row_bytes, voff_a, voff_b, r_begin, r_end, h, a_live, acc, bsum);
-    else dw_rows<NCA, true, false>(gbase, xbase, ga_row_bytes, voff_a, voff_b, r_begin, r_end, h, a_live, acc, bsum);
-  }
+  // workgroup-uniform: every wave's whole range lies inside the pass (then all of them run the pipelined loop, the same
+  // number of rounds, and may meet at barriers); otherwise all of them take the simple ragged-tail loop
+  const bool wg_full = (long long)(lw + 1) * per_wg <= Mrows;
+  // measured at 3,072 rows per workgroup: fenced 1.04 ms per 256 x 256 product (waves finish together, but run in lockstep:
+  // their load phases coincide), unfenced 0.72-0.79 ms -- so no fence while every product has its own launch
+  const bool fence = false;
+  // (the column sums as a runtime flag: as a template parameter the summing waves' loop was scheduled with a full wait per
+  // stage and those two waves held the whole workgroup back -- 12.4 ms instead of 7.7 for the phase)
+  if (NCA == 4) {
+    if (r_begin < r_end) {
+      if (r_nom <= Mrows) dw_rows4<false>(gp, xp, r_begin, r_end, h, do_bias, acc4(acc), bsum);
+      else dw_rows4<true>(gp, xp, r_begin, r_end, h, do_bias, acc4(acc), bsum);
+    }
+  } else if (wg_full) dw_rows<NCA, false>(fence, do_bias, gp, xp, ga_row_floats, r_begin, r_end, h, a_live, acc, bsum);
+  else if (r_begin < r_end) dw_rows<NCA, true>(false, do_bias, gp, xp, ga_row_floats, r_begin, r_end, h, a_live, acc, bsum);
   // this wave's slab block and its 128 column sums (zeros where it did not sum)
-  float* wg = slabs + p.slab_off + (size_t)blockIdx.x * dwi_wg_floats(p);
+  float* wg = slabs + p.slab_off + (size_t)lw * dwi_wg_floats(p);
   float* ws = wg + (size_t)wv * dwi_wave_floats(p);
 #pragma unroll
   for (int ca = 0; ca < NCA; ++ca)
@@ -285,13 +301,21 @@ __global__ __launch_bounds__(512, 2) void k_dw(const DwItem p, const long long M
   }
 #ifdef NERF_STAMPS
   if (p.stamps && lane == 0) {  // per wave: 100 MHz timestamps, XCC and hardware ids (workgroup = blockIdx.x, wave wv)
-    unsigned long long* r = p.stamps + ((size_t)blockIdx.x * 8 + wv) * 4;
+    unsigned long long* r = p.stamps + ((size_t)lw * 8 + wv) * 4;
     r[0] = t_start;
     r[1] = __builtin_amdgcn_s_memrealtime();
     r[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
     r[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
   }
 #endif
+}
+
+// One launch per product, one kernel per block shape -- deliberately small kernels: with both shapes (or a table of products) in
+// one kernel the compiler schedules the big products' loop differently (a full wait per stage, 1.5x slower).  A single launch
+// for all products, the CUs dealt out in proportion to their MFMA time, was also built and measured: 22 ms instead of 7.7.
+template <int NCA>
+__global__ __launch_bounds__(512, 2) void k_dw(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
+  dw_item<NCA>(p, (int)blockIdx.x, Mtot, slabs);
 }
 
 // Sums the slabs of every product of the step and scatters into the nn.Linear-layout gradients: grid (blocks, items).
@@ -310,10 +334,12 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
     int r = e - blk * (int)wave_floats;
     for (int ms = 0; ms < msubs; ++ms) {  // fixed order: msub, then workgroup, four partial sums
       const float* q = base + (size_t)(ms * nblocks + blk) * wave_floats + r;
-      for (int k = 0; k < DW_WGS; k += 4) {
+      int k = 0;
+      for (; k + 4 <= p.nwg; k += 4) {
         s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
         s2 += q[(size_t)(k + 2) * wg_floats]; s3 += q[(size_t)(k + 3) * wg_floats];
       }
+      for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
     }
     const float s = (s0 + s1) + (s2 + s3);
     const int lane = r & 63; r >>= 6;
@@ -335,32 +361,37 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
     const int o = e - n_w;  // column of G (thin: column of A)
     const float* bs = base + DW_WAVES * wave_floats;
     if (p.thin) {
-      for (int k = 0; k < DW_WGS; k += 2) { s0 += bs[(size_t)k * wg_floats + 4 * o]; s1 += bs[(size_t)(k + 1) * wg_floats + 4 * o]; }
-      const float s = s0 + s1;
+      for (int k = 0; k < p.nwg; ++k) s0 += bs[(size_t)k * wg_floats + 4 * o];
+      const float s = s0;
       if (o < 3) p.db[o] = s; else p.db2[0] = s;  // db_color[3], db_sigma
     } else {
       const int ob = o / 128, oi = o % 128;
       for (int w = 0; w < DW_WAVES; ++w) {
         if (((w % nblocks) / in_blocks) != ob || ((w % nblocks) % in_blocks) != 0) continue;  // the waves that summed these G columns
         const float* q = bs + (size_t)w * 128 + oi;
-        for (int k = 0; k < DW_WGS; k += 4) {
+        int k = 0;
+        for (; k + 4 <= p.nwg; k += 4) {
           s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
           s2 += q[(size_t)(k + 2) * wg_floats]; s3 += q[(size_t)(k + 3) * wg_floats];
         }
+        for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
       }
       p.db[o] = (s0 + s1) + (s2 + s3);
     }
   }
 }
 
-size_t dw_item_slab_floats(const DwItem& p) { return (size_t)DW_WGS * dwi_wg_floats(p); }
+size_t dw_item_slab_floats(const DwItem& p) { return (size_t)p.nwg * dwi_wg_floats(p); }
 
-hipError_t launch_dw(const DwItem& p, long long Mtot, float* slabs, hipStream_t st) {
-  if (p.thin)
-    hipLaunchKernelGGL((k_dw<1>), dim3(DW_WGS), dim3(512), 0, st, p, Mtot, slabs);
-  else
-    hipLaunchKernelGGL((k_dw<4>), dim3(DW_WGS), dim3(512), 0, st, p, Mtot, slabs);
-  return hipGetLastError();
+hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st) {
+  for (int i = 0; i < b.n; ++i) {
+    const DwItem& p = b.item[i];
+    if (p.thin) hipLaunchKernelGGL((k_dw<1>), dim3(p.nwg), dim3(512), 0, st, p, Mtot, slabs);
+    else hipLaunchKernelGGL((k_dw<4>), dim3(p.nwg), dim3(512), 0, st, p, Mtot, slabs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st) {

@@ -44,15 +44,18 @@ __device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, co
     unsigned mn = 0;
     if (MASK_IN) {
       if (t + 1 < KT) mn = mask_word(mlayer, t + 1);
-      else if (HAS_NEXT_MASK) mfirst = mask_word(mnext, 0);
+      else if (mnext != nullptr) mfirst = mask_word(mnext, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) tin[t & 1][r] = MASK_IN ? (((mw >> r) & 1u) ? prev[t][r] : 0.f) : prev[t][r];
-    // pin the activated tile to this program point (see k_field_fwd_reg), then stream it out: STORE is a compile-time
-    // property of the call, so the MFMA stream carries no pointer test
+    // Runtime pointer tests on purpose: measured, the uniform branches they leave in the stream make the kernel FASTER than
+    // compile-time flags do (fine pass 5.10 vs 5.46 ms at cfg2) -- they cut the 9,000-MFMA stream into scheduling regions the
+    // compiler handles better than one huge block.  A tile that is not stored is pinned to this program point instead.
+    if (grow == nullptr) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));
-    if (STORE) {
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));
+    }
+    if (grow != nullptr) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) =
@@ -233,11 +236,16 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
   // ---- dpre_0 = d h0 masked; fine: d gamma_p += W_0^T dpre_0
   if (FINE) {
     reg_layer_bwd<32, 2, 32, 2, false, true, true, false>(wp + seg_off4(SEG_T_L0), nullptr, lane, A, accg, st0, mlayer(0), nullptr, mfirst, grow);
-    // gamma -> point -> depth.  accg[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of pair pi = 4(4t+g) + 2h + e
+    // gamma -> point -> depth.  accg[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of pair pi = 4(4t+g) + 2h + e.
+    // d gamma / d x needs (cos, -sin) of the same phases: they ARE the saved layer-0 input (tensor S_GP: this lane's eight
+    // 16-byte groups hold exactly its pairs), so they are loaded, not recomputed -- 8 loads instead of ~15 sincos with their
+    // float64 argument reductions behind the last MFMA, where nothing overlaps them.
     const int ray = mc / a.N;
     const float* rf = a.rayf + (size_t)ray * RAYF;
-    float p[3];
-    sample_point(rf, a.t[mc], p);
+    const float* gprow = srow + S_GP * MS;
+    float4 gq[8];
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) gq[g8] = *reinterpret_cast<const float4*>(gprow + 8 * g8);
     float dp[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8)
@@ -246,10 +254,8 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
         const int pi = 4 * g8 + 2 * h + e;
         if (pi < 30) {
           const int c = pi / 10, l = pi - 10 * c;
-          const float x = (c == 0) ? p[0] : ((c == 1) ? p[1] : p[2]);
           const float fl = __uint_as_float(kFreqPointBits[l]);
-          float sn, cn;
-          sincos_phase(x * fl, sn, cn);
+          const float sn = e == 0 ? gq[g8].x : gq[g8].z, cn = e == 0 ? gq[g8].y : gq[g8].w;
           const float dgs = accg[g8 >> 2][4 * (g8 & 3) + 2 * e], dgc = accg[g8 >> 2][4 * (g8 & 3) + 2 * e + 1];
           const float contrib = fl * (cn * dgs - sn * dgc);
           if (c == 0) dp[0] += contrib; else if (c == 1) dp[1] += contrib; else dp[2] += contrib;

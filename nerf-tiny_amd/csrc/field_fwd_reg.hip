@@ -83,8 +83,6 @@ __device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const 
         *reinterpret_cast<float4*>(sv.rows + 32 * t + 8 * g) =
             make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
       if (RELU_IN) {
-        // bit r = (prev > 0) = (relu'd value > 0): 0.0f - x is negative exactly then (+0 for either zero), and one
-        // v_alignbit shifts that sign bit into the word: 2 VALU per value instead of compare + select + or
         unsigned bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bits |= (prev[t][r] > 0.f) ? (1u << r) : 0u;

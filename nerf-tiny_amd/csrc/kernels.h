@@ -159,10 +159,11 @@ struct DwItem {
   float* db;               // [nout] bias gradient = column sums of G, or null                 (thin: db_color[3])
   float* dW2; float* db2;  // thin only: dw_sigma[256], db_sigma[1]
   int thin;                // 1: the colour + sigma heads as one product
+  int wg0, nwg;            // workgroups [wg0, wg0 + nwg) of the launch work on this product, each on 1/nwg of the rows
   long long slab_off;      // floats: this product's slabs inside DwBatch::slabs
   unsigned long long* stamps;  // diagnostic build only: per-wave (start, end, xcc, hw id) records
 };
-constexpr int DW_WGS = 256;  // one workgroup per CU
+constexpr int DW_WGS = 256;  // workgroups of the launch: one per CU, dealt out over the products
 constexpr int DW_MAX_ITEMS = 13;
 struct DwBatch {
   DwItem item[DW_MAX_ITEMS];
@@ -217,7 +218,7 @@ hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned c
                                 hipStream_t st);
 hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count,
                                  float* dW, int ldw, int col0, float* db, hipStream_t st);
-hipError_t launch_dw(const DwItem& p, long long Mtot, float* slabs, hipStream_t st);  // one product -> its slabs
+hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st);  // every product -> its slabs, ONE launch
 hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st);                         // all slabs of the step -> gradients
 size_t dw_item_slab_floats(const DwItem& p);
 hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st);
