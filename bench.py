@@ -178,14 +178,17 @@ def cpu_baseline(seconds_budget=25.0):
     return out
 
 
-def read_traffic(kernel_key):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summary (scripts/profile_pmc.sh +
-    scripts/summarize_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction).
+def read_traffic(kernel_keys, train=False, scale=None):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summaries (scripts/profile_pmc.sh + scripts/summarize_pmc.py:
+    separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction): the mean over `kernel_keys`
+    (per-kernel averages over their launches), or with `scale` = {key: launches per step} their sum per step.
     Not measured in this run: the block says so in `traffic_source`."""
-    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    p = os.path.join(ROOT, "profiles", "pmc_train_latest.json" if train else "pmc_latest.json")
     try:
         with open(p) as f:
-            return json.load(f).get(kernel_key, {}).get("hbm_bytes_per_launch")
+            d = json.load(f)
+        vals = [d[k]["hbm_bytes_per_launch"] * (scale[k] if scale else 1) for k in kernel_keys]
+        return int(sum(vals) if scale else sum(vals) / len(vals))
     except Exception:
         return None
 
@@ -265,21 +268,23 @@ def rooflines(leg, prof, b_local, steps):
         avg = ms / max(n, 1)
         ach = flop_per_launch / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
         blk = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-               "traffic": read_traffic(traffic_key) if traffic_key else None, "kernel": kernel, "avg_launch_ms": round(avg, 4),
+               "traffic": read_traffic(traffic_key, train=leg.train) if traffic_key else None, "kernel": kernel, "avg_launch_ms": round(avg, 4),
                "launches": n, "flop_per_launch": flop_per_launch}
         if traffic_key:
-            blk["traffic_source"] = "profiles/pmc_latest.json (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
+            blk["traffic_source"] = ("profiles/pmc_train_latest.json" if leg.train else "profiles/pmc_latest.json") + \
+                " (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
         return blk
 
     # dominant forward kernel: launched twice per step (coarse pass B*Nc samples, fine pass B*Nf samples); "launch" = the
     # average launch, so that rocprofv3's per-kernel average is directly comparable
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
     fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
-               FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, None if (leg.bf16 or leg.train) else "k_field_fwd")
+               FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, None if leg.bf16 else ["k_field_fwd"])
     if not leg.train:
         return fwd, None
     chain = mfma(("k_field_bwd_bf16" if leg.bf16 else "k_field_bwd_reg") + " (dX chain; average of the fine- and coarse-pass launches)",
-                 ("bwd_field_fine", "bwd_field_coarse"), (CHAIN_FLOP_COARSE * b_local * NC + CHAIN_FLOP_FINE * b_local * NF) // 2)
+                 ("bwd_field_fine", "bwd_field_coarse"), (CHAIN_FLOP_COARSE * b_local * NC + CHAIN_FLOP_FINE * b_local * NF) // 2,
+                 None if leg.bf16 else ["k_field_bwd_reg<true>", "k_field_bwd_reg<false>"])
     # weight-gradient phase: all dW = G^T X products of one step (same MACs as one forward over all samples) + slab reduces + thin heads
     dw_ms = prof.get("bwd_dw", (0.0, 0))[0] / max(prof.get("bwd_dw", (0.0, 1))[1], 1)
     if leg.bf16:
@@ -293,7 +298,9 @@ def rooflines(leg, prof, b_local, steps):
     else:
         flop = FLOP_PER_SAMPLE * b_local * (NC + NF)
         ach = flop / (dw_ms * 1e-3) / 1e12 if dw_ms > 0 else 0.0
-        dw = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+        dw = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+              "traffic": read_traffic(["k_dw<4>", "k_dw<1>", "k_dw_reduce"], train=True, scale={"k_dw<4>": 11, "k_dw<1>": 1, "k_dw_reduce": 1}),
+              "traffic_source": "profiles/pmc_train_latest.json (committed rocprofv3 --pmc passes; 11 k_dw<4> + k_dw<1> + k_dw_reduce per step)",
               "kernel": "k_dw (all weight-gradient products of one step incl. reduces and thin heads = one 'launch')",
               "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "flop_per_launch": flop}
     phases = {"forward_with_saves": fwd, "dx_chain": chain, "dw": dw}

@@ -30,6 +30,8 @@ p = os.path.join(root, "profiles", f"{tag}_{mode}_pmc.json")
 json.dump(out, open(p, "w"), indent=1, sort_keys=True)
 if mode == "forward":
     json.dump(out, open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+if mode == "train_f32":
+    json.dump(out, open(os.path.join(root, "profiles", "pmc_train_latest.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(out):
     if "field" in k or k.startswith("k_dw"):
         print(k, json.dumps(out[k], sort_keys=True))

@@ -41,6 +41,12 @@ def max_rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def elementwise_rel(a, b, floor=1e-6):
+    """max over elements of |a-b| / max(|b|, floor): the element-wise reading of 'rel' (north_star: 1e-4 rel fp32)."""
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float(((a - b).abs() / b.abs().clamp_min(floor)).max())
+
+
 def l2_rel(a, b):
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
