@@ -94,6 +94,75 @@ __device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, co
   }
 }
 
+// The 2-tile segments (d gamma_p: layer 4's skip columns and layer 0, fine pass only): 8 MFMAs per k-block instead of 32, so a
+// fragment requested one k-block ahead arrives 512 cycles later -- less than an L2 round trip, and the wave sat out a part of
+// it on every k-block (stamped: 47 k cycles for 8 k of MFMA in layer 0).  Here the 16 fragment registers of the two stages
+// form a ring of 8 k-blocks: requests run 8 k-blocks (4096 cycles) ahead.  st0.w[0..1] = k-block 0 on entry; on exit st0
+// holds the next segment's k-block 0 (NNFT tiles), requested at k-block KB - 4 when st0's half of the ring has drained.
+template <int KB, int NKB, int NNFT, bool ZERO_INIT, bool STORE, bool HAS_NEXT_MASK>
+__device__ __forceinline__ void reg_layer_bwd_thin(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
+                                                   const f32x16* prev, f32x16* acc, WStageB<8>& st0, const uint16_t* __restrict__ mlayer,
+                                                   const uint16_t* __restrict__ mnext, unsigned& mfirst, float* __restrict__ grow) {
+  static_assert(KB == 32, "ring indexing below assumes 32 k-blocks");
+  constexpr int KT = KB / 4, D = 8;
+  const float4* sl = seg + lane;
+  const float4* nl = next_seg + lane;
+  WStageB<8> st1;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 tin[2];
+  unsigned mw = mfirst;
+  auto slot = [&](int kb, int f) -> float4& { return ((kb % D) < 4) ? st0.w[2 * (kb % 4) + f] : st1.w[2 * (kb % 4) + f]; };
+  auto activate = [&](int t) {
+    unsigned mn = 0;
+    if (t + 1 < KT) mn = mask_word(mlayer, t + 1);
+    else if (HAS_NEXT_MASK) mfirst = mask_word(mnext, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tin[t & 1][r] = ((mw >> r) & 1u) ? prev[t][r] : 0.f;
+    if (STORE) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) =
+            make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));
+    }
+    mw = mn;
+  };
+  // fill the ring: k-blocks 1 .. D-1 (k-block 0 came with the previous segment)
+#pragma unroll
+  for (int kb = 1; kb < D; ++kb)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) slot(kb, f) = sl[(size_t)(f * KB + kb) * 64];
+  activate(0);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if ((kb & 3) == 2 && (kb >> 2) + 1 < KT) activate((kb >> 2) + 1);
+    const float4 w0 = slot(kb, 0), w1 = slot(kb, 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float b = tin[(kb >> 2) & 1][4 * (kb & 3) + s];
+      if (ZERO_INIT && kb == 0 && s == 0) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4cb(w0, s), b, zero, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4cb(w1, s), b, zero, 0, 0, 0);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4cb(w0, s), b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4cb(w1, s), b, acc[1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the slot just consumed takes k-block kb + D; once the ring's st0 half has drained for good it takes the next segment
+    if (kb + D < KB) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) slot(kb, f) = sl[(size_t)(f * KB + kb + D) * 64];
+    } else if (kb == KB - 4 && next_seg != nullptr) {
+#pragma unroll
+      for (int f = 0; f < NNFT; ++f) st0.w[f] = nl[(size_t)(f * NKB) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 #ifdef NERF_STAMPS  // diagnostic build only (make stamps): cycle sums per phase, see scripts/phase_stamps.py
 #define BSTAMP(slot)                                            \
   do {                                                          \
@@ -216,7 +285,7 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
   f32x16 accg[2];
   if (FINE) {
     reg_layer_bwd<32, 8, 32, 2, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L4B), lane, A, B, st0, mlayer(4), mlayer(4), mfirst, grow + 4 * MS);
-    reg_layer_bwd<32, 2, 32, 8, true, true, false>(wp + seg_off4(SEG_T_L4B), wp + seg_off4(SEG_T_L3), lane, A, accg, st0, mlayer(4), mlayer(3), mfirst, nullptr);
+    reg_layer_bwd_thin<32, 32, 8, true, false, true>(wp + seg_off4(SEG_T_L4B), wp + seg_off4(SEG_T_L3), lane, A, accg, st0, mlayer(4), mlayer(3), mfirst, nullptr);
   } else {
     reg_layer_bwd<32, 8, 32, 8, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L3), lane, A, B, st0, mlayer(4), mlayer(3), mfirst, grow + 4 * MS);
   }
@@ -235,7 +304,7 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
   BSTAMP(5);  // layers 3..1 (3,072 MFMAs)
   // ---- dpre_0 = d h0 masked; fine: d gamma_p += W_0^T dpre_0
   if (FINE) {
-    reg_layer_bwd<32, 2, 32, 2, false, true, true, false>(wp + seg_off4(SEG_T_L0), nullptr, lane, A, accg, st0, mlayer(0), nullptr, mfirst, grow);
+    reg_layer_bwd_thin<32, 32, 2, false, true, false>(wp + seg_off4(SEG_T_L0), nullptr, lane, A, accg, st0, mlayer(0), nullptr, mfirst, grow);
     // gamma -> point -> depth.  accg[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of pair pi = 4(4t+g) + 2h + e.
     // d gamma / d x needs (cos, -sin) of the same phases: they ARE the saved layer-0 input (tensor S_GP: this lane's eight
     // 16-byte groups hold exactly its pairs), so they are loaded, not recomputed -- 8 loads instead of ~15 sincos with their
