@@ -76,9 +76,7 @@ long long build_dw_batch(DwBatch& b, const float* G, const float* save, const fl
   DwItem& th = add(dz4, 32, St(7), 384, 384, D(W_COLOR), HALF, 0, D(B_COLOR), 0.35f);                  // colour + sigma heads: X = [h7 | c]
   th.thin = 1; th.X2 = St(S_C); th.dW2 = D(W_SIGMA); th.db2 = D(B_SIGMA);
   // Every product gets ALL DW_WGS workgroups in a launch of its own.  (One launch for all products, the CUs dealt out in
-  // proportion to `units`, was built and measured: 22 ms instead of 7.7 -- twelve products streaming 24 operand tensors
-  // concurrently, each workgroup over a 28,000-row range, is not what the memory system likes; workgroup barriers that
-  // keep the waves on the same rows did not help.  See DESIGN.md section 4.)
+  // proportion to `units`, was built and measured: no gain (8.2 vs 8.1 ms for the phase).  See DESIGN.md section 4b.)
   (void)units;
   for (int i = 0; i < b.n; ++i) b.item[i].nwg = DW_WGS;
   long long off = 0;
