@@ -16,6 +16,7 @@
 // Autograd spans replaced: the weight / bias gradients of Network.forward (nerf.py:101-124) as produced by
 // loss.backward() at nerf.py:473.
 #include "field_common.h"
+#include "bf16_stream.h"  // static_for
 
 namespace nerf {
 
@@ -126,181 +127,218 @@ __device__ __forceinline__ void dw_rows(const bool BARRIER, const bool BIAS, con
   }
 }
 
-// The 128 x 64 blocks of the big products run round 1's loop as it stands (same source, same register allocation): this
-// compiler's scheduling of the stage loads is brittle -- three rewrites of this loop (compile-time bias flag, one address per
-// stage, 32-bit row cursor) each compiled into a loop that waits for a stage right after requesting it, 1.5x slower.
-struct DwStage4 {
-  float4 a[DW_UNROLL];
-  float2 b[DW_UNROLL];
+// ---- one wave per SIMD: a 128 x (32 NCB) output block per wave (256 / 128 accumulators), no SIMD partner ---------------------
+// Two waves per SIMD do not share the matrix pipe evenly (the older wave wins every arbitration, ends at 78 % of the kernel's
+// time and leaves its partner latency-bound).  Here a SIMD has ONE wave, which hides the memory
+// latency itself: a ring of DW4_DEPTH k-steps (one 16-byte load per operand and k-step), DW4_DEPTH - 1 of them (7 x 1024 MFMA
+// cycles = 3 us) requested ahead of the one being multiplied.  Per k-step: 2 vector-memory instructions for 16 (8) MFMAs.
+constexpr int DW4_DEPTH = 8;
+
+template <int NCB> struct DwVecB;
+template <> struct DwVecB<4> { typedef float4 type; };
+template <> struct DwVecB<2> { typedef float2 type; };
+
+template <int NCB>
+struct DwFrag {
+  float4 a;
+  typename DwVecB<NCB>::type b;
 };
 
-// main loop of k_dw over rows [r_begin, r_end).  CHECK = false: every row of every stage is in range (no selects
-// between the loads and their use, so the loads of two stages stay in flight behind the MFMAs of the third).
-template <bool CHECK>
-__device__ __forceinline__ void dw_rows4(const float* __restrict__ gp, const float* __restrict__ xp, long long r_begin,
-                                        long long r_end, int h, bool do_bias, f32x16 (&acc)[4][2], float (&bsum)[4]) {
-  auto load = [&](long long r0, DwStage4& S) {
+// rows [r_begin, r_end) (wave-uniform, a multiple of 2 DW4_DEPTH rows long unless CHECK).  gbase / xbase: wave-uniform
+// operand pointers at row 0; goff / xoff: this lane's byte offset inside a row pair (row h, column group q), so that a load
+// is `global_load v, v_off, s[base]` with the row advance in scalar registers.
+template <int NCB, bool BIAS>
+__device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const float* __restrict__ xbase, const unsigned goff, const unsigned xoff,
+                                          const int r_begin, const int r_end, f32x16 (&acc)[4][NCB], float (&bsum)[4]) {
+  typedef typename DwVecB<NCB>::type VB;
+  constexpr int D = DW4_DEPTH;
+  DwFrag<NCB> s[D];
+  const int r_last = r_end - 2;
+  auto load = [&](int r, DwFrag<NCB>& S) {
+    r = r <= r_last ? r : r_last;  // the prefetches past the end re-read the last row pair (valid memory, never multiplied)
+    const char* ga = reinterpret_cast<const char*>(gbase + (size_t)r * WIDTH);
+    const char* xa = reinterpret_cast<const char*>(xbase + (size_t)r * WIDTH);
+    S.a = *reinterpret_cast<const float4*>(ga + goff);
+    S.b = *reinterpret_cast<const VB*>(xa + xoff);
+  };
+  auto mul = [&](const DwFrag<NCB>& S) {
 #pragma unroll
-    for (int u = 0; u < DW_UNROLL; ++u) {
-      // both operands have row stride WIDTH floats (all buffers of the workspace do)
-      if (CHECK) {
-        long long r = r0 + 2 * u + h;
-        r = r < r_end ? r : r_end - 1;
-        S.a[u] = *reinterpret_cast<const float4*>(gp + (size_t)r * WIDTH);
-        S.b[u] = *reinterpret_cast<const float2*>(xp + (size_t)r * WIDTH);
-      } else {
-        const size_t off = (size_t)(r0 + h) * WIDTH + (size_t)u * 2 * WIDTH;
-        S.a[u] = *reinterpret_cast<const float4*>(gp + off);
-        S.b[u] = *reinterpret_cast<const float2*>(xp + off);
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        float bv;
+        if constexpr (NCB == 4) bv = comp(S.b, cb); else bv = comp(S.b, cb);
+        acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(S.a, ca), bv, acc[ca][cb], 0, 0, 0);
       }
+    if (BIAS) {
+      // as asm statements: plain adds get re-associated across the ring, the stage loads follow them, and the loop ends up
+      // requesting all eight stages at once
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[0]) : "v"(S.a.x));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[1]) : "v"(S.a.y));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[2]) : "v"(S.a.z));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[3]) : "v"(S.a.w));
     }
   };
-  auto mul = [&](long long r0, const DwStage4& S) {
-#pragma unroll
-    for (int u = 0; u < DW_UNROLL; ++u) {
-      float4 a = S.a[u];
-      if (CHECK) {
-        if (r0 + 2 * u + h >= r_end) a = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the end contribute nothing
-      }
-#pragma unroll
-      for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(S.b[u], cb), acc[ca][cb], 0, 0, 0);
-      if (do_bias) {
-        bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w;
-      }
-    }
-  };
-  constexpr long long G = 2 * DW_UNROLL;  // rows per stage
-  DwStage4 s0, s1, s2;
-  // branch-free rotation: the two prefetches past the end re-read the last stage (valid memory, never multiplied)
-  const long long r_last = CHECK ? r_end : r_end - G;
-  auto at = [&](long long r) { return (CHECK || r <= r_last) ? r : r_last; };
-  load(r_begin, s0);
-  load(at(r_begin + G), s1);
-  for (long long r0 = r_begin; r0 < r_end; r0 += 3 * G) {
-    // the scheduling barriers keep each stage's requests where they are written: two stages (64 MFMAs) ahead of
-    // their use -- left alone the compiler sinks them next to the uses and every iteration waits on HBM
-    load(at(r0 + 2 * G), s2);
+  static_for<D - 1>([&](auto I) {  // in ring order (left alone the scheduler issues them last to first, and the loop's first wait drains the ring)
+    load(r_begin + 2 * (int)I, s[I]);
     __builtin_amdgcn_sched_barrier(0);
-    mul(r0, s0);
-    __builtin_amdgcn_sched_barrier(0);
-    load(at(r0 + 3 * G), s0);
-    __builtin_amdgcn_sched_barrier(0);
-    mul(r0 + G, s1);
-    __builtin_amdgcn_sched_barrier(0);
-    load(at(r0 + 4 * G), s1);
-    __builtin_amdgcn_sched_barrier(0);
-    mul(r0 + 2 * G, s2);
-    __builtin_amdgcn_sched_barrier(0);
+  });
+  for (int r0 = r_begin; r0 < r_end; r0 += 2 * D) {
+    static_for<D>([&](auto I) {
+      constexpr int i = I;
+      load(r0 + 2 * (i + D - 1), s[(i + D - 1) % D]);
+      __builtin_amdgcn_sched_barrier(0);
+      mul(s[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
 }
 
+// ragged tail of a pass (a few waves of a launch): one row pair at a time, rows clamped per lane, rows past the end contribute 0
+template <int NCB>
+__device__ __forceinline__ void dw_stream_tail(const float* __restrict__ gbase, const float* __restrict__ xbase, const unsigned goff, const unsigned xoff,
+                                               const int h, const int r_begin, const int r_end, const bool do_bias, f32x16 (&acc)[4][NCB], float (&bsum)[4]) {
+  typedef typename DwVecB<NCB>::type VB;
+  for (int r0 = r_begin; r0 < r_end; r0 += 2) {
+    const bool live = r0 + h < r_end;
+    const int r = live ? r0 : r_end - 1 - h;  // (row r + h of the lane's offsets = r_end - 1)
+    float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gbase + (size_t)r * WIDTH) + goff);
+    const VB b = *reinterpret_cast<const VB*>(reinterpret_cast<const char*>(xbase + (size_t)r * WIDTH) + xoff);
+    if (!live) a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(b, cb), acc[ca][cb], 0, 0, 0);
+    if (do_bias) { bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w; }
+  }
+}
 
 }  // namespace
 
-// geometry of one product, shared by the kernel, the reduce and the host
-__host__ __device__ inline int dwi_in_blocks(const DwItem& p) { return p.thin ? 6 : p.nin / 64; }
-__host__ __device__ inline int dwi_nblocks(const DwItem& p) { return p.thin ? 6 : (p.nout / 128) * (p.nin / 64); }  // 8, 4, 2 (thin: 6 of 8 waves)
-__host__ __device__ inline int dwi_msubs(const DwItem& p) { return p.thin ? 1 : DW_WAVES / dwi_nblocks(p); }
-__host__ __device__ inline size_t dwi_wave_floats(const DwItem& p) { return (size_t)(p.thin ? 1 : 4) * 2 * 16 * 64; }
-// per workgroup: 8 wave blocks + 8 x 128 column sums
-__host__ __device__ inline size_t dwi_wg_floats(const DwItem& p) { return DW_WAVES * (dwi_wave_floats(p) + 128); }
+// geometry of one product, shared by the kernels, the reduce and the host
+__host__ __device__ inline int dwi_ncb(const DwItem& p) { return p.thin ? 2 : (p.nin % 128 == 0 ? 4 : 2); }  // 32-column tiles of X per wave
+__host__ __device__ inline int dwi_waves(const DwItem& p) { return p.thin ? DW_WAVES : 4; }
+__host__ __device__ inline int dwi_in_blocks(const DwItem& p) { return p.thin ? 6 : p.nin / (32 * dwi_ncb(p)); }
+__host__ __device__ inline int dwi_nblocks(const DwItem& p) { return p.thin ? 6 : (p.nout / 128) * dwi_in_blocks(p); }  // 4, 2 (thin: 6 of 8 waves)
+__host__ __device__ inline int dwi_msubs(const DwItem& p) { return p.thin ? 1 : dwi_waves(p) / dwi_nblocks(p); }
+__host__ __device__ inline size_t dwi_wave_floats(const DwItem& p) { return (size_t)(p.thin ? 1 : 4) * dwi_ncb(p) * 16 * 64; }
+// per workgroup: one block per wave + 128 column sums per wave
+__host__ __device__ inline size_t dwi_wg_floats(const DwItem& p) { return dwi_waves(p) * (dwi_wave_floats(p) + 128); }
 
-// One workgroup's share of one product: rows [lw, lw + 1) * per_wg of its `nwg` workgroups (lw = workgroup index inside the
-// product).
-template <int N>
-__device__ __forceinline__ f32x16 (&acc4(f32x16 (&a)[N][2]))[4][2] { return reinterpret_cast<f32x16 (&)[4][2]>(a); }
-
-template <int NCA>
-__device__ __forceinline__ void dw_item(const DwItem& p, const int lw, const long long Mtot, float* __restrict__ slabs) {
-  const int tid = threadIdx.x, lane = tid & 63;
+// The thin heads as one product: A = the [rows][4] buffer, one 32-row output tile per wave, X = [h7 | c] in six 64-column blocks
+// (waves 6, 7 idle), every workgroup on 1/nwg of the rows.
+__global__ __launch_bounds__(512, 2) void k_dw_thin(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
+  const int tid = threadIdx.x, lane = tid & 63, lw = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform values stay in SGPRs from here on
+  constexpr int nblocks = 6;
+  if (wv >= nblocks) return;
+  const int blk = wv;
+  const int gran = DW_ROWS * DW_STAGES;
+  const int Mrows = (int)Mtot;  // < 2^31 rows and < 4 GiB per operand (checked by the host)
+  const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran;  // a multiple of the 24 rows of one pipeline round
+  const long long r_begin64 = (long long)lw * per_wg;
+  const int r_begin = r_begin64 < Mrows ? (int)r_begin64 : Mrows;
+  const long long r_nom = r_begin64 + per_wg;
+  const int r_end = r_nom > Mrows ? Mrows : (int)r_nom;
+  const int h = lane >> 5, q = lane & 31;
+
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][cb][r] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const float* gp = p.G + (q & 3);  // [rows][4]
+  const float* xp = (blk < 4 ? p.X + blk * 64 : p.X2 + (blk - 4) * 64) + 2 * q;
+  const bool do_bias = blk == 0;  // wave-uniform: column sums of A on this wave
+  const bool a_live = q < 4;
+  if (r_nom <= Mrows) dw_rows<1, false>(false, do_bias, gp, xp, 4, r_begin, r_end, h, a_live, acc, bsum);
+  else if (r_begin < r_end) dw_rows<1, true>(false, do_bias, gp, xp, 4, r_begin, r_end, h, a_live, acc, bsum);
+  // this wave's slab block and its column sums (entry 4q: column sum of A column q; zeros where it did not sum)
+  float* wg = slabs + p.slab_off + (size_t)lw * dwi_wg_floats(p);
+  float* ws = wg + (size_t)wv * dwi_wave_floats(p);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ws[((size_t)cb * 16 + r) * 64 + lane] = acc[0][cb][r];
+  bsum[0] += __shfl_xor(bsum[0], 32);
+  if (h == 0) {
+    float* bs = wg + DW_WAVES * dwi_wave_floats(p) + (size_t)wv * 128;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bs[4 * q + c] = (c == 0 && q < 4) ? bsum[0] : 0.f;
+  }
+}
+
+// One workgroup's share of one big product, 4 waves: wave = (block, row sub-range); block = 128 columns of G x 32 NCB columns of X.
+template <int NCB>
+__global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
+  const int lane = threadIdx.x & 63, lw = blockIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef NERF_STAMPS
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int in_blocks = dwi_in_blocks(p);
-  const int nblocks = dwi_nblocks(p);
-  const int msubs = dwi_msubs(p);
+  const int in_blocks = p.nin / (32 * NCB);
+  const int nblocks = (p.nout / 128) * in_blocks;
+  const int msubs = 4 / nblocks;
   const int blk = wv % nblocks, msub = wv / nblocks;
-  if (NCA == 1 && wv >= nblocks) return;  // thin heads: waves 6, 7 have no block
-  const int oA = NCA == 1 ? 0 : (blk / in_blocks) * 128;
-  const int gran = DW_ROWS * DW_STAGES * msubs;
+  const int gran = 2 * DW4_DEPTH * msubs;
   const int Mrows = (int)Mtot;  // < 2^31 rows and < 4 GiB per operand (checked by the host)
   const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran;
-  const int per_wave = per_wg / msubs;  // a multiple of the 24 rows of one pipeline round
+  const int per_wave = per_wg / msubs;  // a multiple of the 2 DW4_DEPTH rows of one ring round
   const long long r_begin64 = (long long)lw * per_wg + (long long)msub * per_wave;
   const int r_begin = r_begin64 < Mrows ? (int)r_begin64 : Mrows;
   const long long r_nom = r_begin64 + per_wave;
   const int r_end = r_nom > Mrows ? Mrows : (int)r_nom;
   const int h = lane >> 5, q = lane & 31;
 
-  f32x16 acc[NCA][2];
+  f32x16 acc[4][NCB];
 #pragma unroll
-  for (int ca = 0; ca < NCA; ++ca)
+  for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-  // this lane's operand pointers at row 0
-  const float* gp;
-  const float* xp;
-  int ga_row_floats;
-  bool do_bias;  // wave-uniform: column sums of A on this wave
-  if (NCA == 4) {
-    gp = p.G + oA + 4 * q;
-    xp = p.X + (blk % in_blocks) * 64 + 2 * q;
-    ga_row_floats = WIDTH;
-    // column sums of G = bias gradient: one of the in_blocks waves that read the same G columns does them (4 adds per k-step;
-    // two such waves per workgroup, on different SIMDs)
-    do_bias = p.db != nullptr && (blk % in_blocks) == 0;
-  } else {
-    gp = p.G + (q & 3);  // [rows][4]
-    xp = (blk < 4 ? p.X + blk * 64 : p.X2 + (blk - 4) * 64) + 2 * q;
-    ga_row_floats = 4;
-    do_bias = blk == 0;
-  }
-  const bool a_live = q < 4;
-  // workgroup-uniform: every wave's whole range lies inside the pass (then all of them run the pipelined loop, the same
-  // number of rounds, and may meet at barriers); otherwise all of them take the simple ragged-tail loop
-  const bool wg_full = (long long)(lw + 1) * per_wg <= Mrows;
-  // measured at 3,072 rows per workgroup: fenced 1.04 ms per 256 x 256 product (waves finish together, but run in lockstep:
-  // their load phases coincide), unfenced 0.72-0.79 ms -- so no fence while every product has its own launch
-  const bool fence = false;
-  // (the column sums as a runtime flag: as a template parameter the summing waves' loop was scheduled with a full wait per
-  // stage and those two waves held the whole workgroup back -- 12.4 ms instead of 7.7 for the phase)
-  if (NCA == 4) {
-    if (r_begin < r_end) {
-      if (r_nom <= Mrows) dw_rows4<false>(gp, xp, r_begin, r_end, h, do_bias, acc4(acc), bsum);
-      else dw_rows4<true>(gp, xp, r_begin, r_end, h, do_bias, acc4(acc), bsum);
+  const float* gbase = p.G + (blk / in_blocks) * 128;
+  const float* xbase = p.X + (blk % in_blocks) * (32 * NCB);
+  const unsigned goff = (unsigned)(h * WIDTH + 4 * q) * 4u, xoff = (unsigned)(h * WIDTH + NCB * q) * 4u;
+  // column sums of G = bias gradient: the wave of input block 0 does them for its 128 columns of G (4 adds per k-step)
+  const bool do_bias = p.db != nullptr && (blk % in_blocks) == 0;
+  if (r_begin < r_end) {
+    if (r_nom <= Mrows) {
+      // (the empty asm statements differ on purpose: identical starts of the two branches get hoisted into this block, and the
+      // summing variant's loop then waits for the whole ring at every k-step)
+      if (do_bias) {
+        asm volatile("; column sums" ::: "memory");
+        dw_stream<NCB, true>(gbase, xbase, goff, xoff, r_begin, r_end, acc, bsum);
+      } else {
+        asm volatile("; no column sums" ::: "memory");
+        dw_stream<NCB, false>(gbase, xbase, goff, xoff, r_begin, r_end, acc, bsum);
+      }
+    } else {
+      dw_stream_tail<NCB>(gbase, xbase, goff, xoff, h, r_begin, r_end, do_bias, acc, bsum);
     }
-  } else if (wg_full) dw_rows<NCA, false>(fence, do_bias, gp, xp, ga_row_floats, r_begin, r_end, h, a_live, acc, bsum);
-  else if (r_begin < r_end) dw_rows<NCA, true>(false, do_bias, gp, xp, ga_row_floats, r_begin, r_end, h, a_live, acc, bsum);
-  // this wave's slab block and its 128 column sums (zeros where it did not sum)
-  float* wg = slabs + p.slab_off + (size_t)lw * dwi_wg_floats(p);
-  float* ws = wg + (size_t)wv * dwi_wave_floats(p);
+  }
+  constexpr size_t wave_floats = (size_t)4 * NCB * 16 * 64;
+  float* wg = slabs + p.slab_off + (size_t)lw * (4 * (wave_floats + 128));
+  float* ws = wg + (size_t)wv * wave_floats;
 #pragma unroll
-  for (int ca = 0; ca < NCA; ++ca)
+  for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ws[((size_t)(ca * 2 + cb) * 16 + r) * 64 + lane] = acc[ca][cb][r];
+      for (int r = 0; r < 16; ++r) ws[((size_t)(ca * NCB + cb) * 16 + r) * 64 + lane] = acc[ca][cb][r];
 #pragma unroll
   for (int c = 0; c < 4; ++c) bsum[c] += __shfl_xor(bsum[c], 32);
   if (h == 0) {
-    float* bs = wg + DW_WAVES * dwi_wave_floats(p) + (size_t)wv * 128;
-    if (NCA == 4) {
+    float* bs = wg + 4 * wave_floats + (size_t)wv * 128;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) bs[4 * q + c] = bsum[c];
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) bs[4 * q + c] = (c == 0 && q < 4) ? bsum[0] : 0.f;  // entry 4q: column sum of A column q
-    }
+    for (int c = 0; c < 4; ++c) bs[4 * q + c] = bsum[c];
   }
 #ifdef NERF_STAMPS
-  if (p.stamps && lane == 0) {  // per wave: 100 MHz timestamps, XCC and hardware ids (workgroup = blockIdx.x, wave wv)
+  if (p.stamps && lane == 0) {  // per wave: 100 MHz timestamps, XCC and hardware ids
     unsigned long long* r = p.stamps + ((size_t)lw * 8 + wv) * 4;
     r[0] = t_start;
     r[1] = __builtin_amdgcn_s_memrealtime();
@@ -310,15 +348,9 @@ __device__ __forceinline__ void dw_item(const DwItem& p, const int lw, const lon
 #endif
 }
 
-// One launch per product, one kernel per block shape -- deliberately small kernels: with both shapes (or a table of products) in
-// one kernel the compiler schedules the big products' loop differently (a full wait per stage, 1.5x slower).  A single launch
-// for all big products, the CUs dealt out in proportion to their MFMA time, was also built and measured (with the loop compiled
-// well): 8.2 ms for the phase instead of 8.1, no gain.
-template <int NCA>
-__global__ __launch_bounds__(512, 2) void k_dw(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
-  dw_item<NCA>(p, (int)blockIdx.x, Mtot, slabs);
-}
-
+// One launch per product, one small kernel per block shape (this compiler schedules the stage loads of a loop differently when
+// other loops share its kernel).  A single launch for all big products, the CUs dealt out in proportion to their MFMA time,
+// was also built and measured in round 2: no gain.
 // Sums the slabs of every product of the step and scatters into the nn.Linear-layout gradients: grid (blocks, items).
 __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
   const DwItem& p = b.item[blockIdx.y];
@@ -345,7 +377,8 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
     const float s = (s0 + s1) + (s2 + s3);
     const int lane = r & 63; r >>= 6;
     const int reg = r & 15; r >>= 4;
-    const int cb = r & 1, ca = r >> 1;
+    const int ncb = dwi_ncb(p);
+    const int cb = r % ncb, ca = r / ncb;
     const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);  // row of the 32 x 32 tile
     if (p.thin) {
       const int out = i;                                  // row of A: 0..2 colour, 3 sigma
@@ -353,21 +386,21 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
       if (in < WIDTH) { if (out == 3) p.dW2[in] = s; }    // dw_sigma[256]
       else if (out < 3) p.dW[(size_t)out * HALF + (in - WIDTH)] = s;  // dW_color[3][128]
     } else {
-      const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * 64;
+      const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * 32 * ncb;
       const int out = oA + 4 * i + ca;
-      const int in = iB + 2 * (lane & 31) + cb;
+      const int in = iB + ncb * (lane & 31) + cb;
       if (in < p.nin_real) p.dW[(size_t)out * p.ldw + p.col0 + in] = s;
     }
   } else {
     const int o = e - n_w;  // column of G (thin: column of A)
-    const float* bs = base + DW_WAVES * wave_floats;
+    const float* bs = base + dwi_waves(p) * wave_floats;
     if (p.thin) {
       for (int k = 0; k < p.nwg; ++k) s0 += bs[(size_t)k * wg_floats + 4 * o];
       const float s = s0;
       if (o < 3) p.db[o] = s; else p.db2[0] = s;  // db_color[3], db_sigma
     } else {
       const int ob = o / 128, oi = o % 128;
-      for (int w = 0; w < DW_WAVES; ++w) {
+      for (int w = 0; w < dwi_waves(p); ++w) {
         if (((w % nblocks) / in_blocks) != ob || ((w % nblocks) % in_blocks) != 0) continue;  // the waves that summed these G columns
         const float* q = bs + (size_t)w * 128 + oi;
         int k = 0;
@@ -387,8 +420,9 @@ size_t dw_item_slab_floats(const DwItem& p) { return (size_t)p.nwg * dwi_wg_floa
 hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st) {
   for (int i = 0; i < b.n; ++i) {
     const DwItem& p = b.item[i];
-    if (p.thin) hipLaunchKernelGGL((k_dw<1>), dim3(p.nwg), dim3(512), 0, st, p, Mtot, slabs);
-    else hipLaunchKernelGGL((k_dw<4>), dim3(p.nwg), dim3(512), 0, st, p, Mtot, slabs);
+    if (p.thin) hipLaunchKernelGGL(k_dw_thin, dim3(p.nwg), dim3(512), 0, st, p, Mtot, slabs);
+    else if (dwi_ncb(p) == 4) hipLaunchKernelGGL((k_dw4<4>), dim3(p.nwg), dim3(256), 0, st, p, Mtot, slabs);
+    else hipLaunchKernelGGL((k_dw4<2>), dim3(p.nwg), dim3(256), 0, st, p, Mtot, slabs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
