@@ -71,10 +71,11 @@ long long build_dw_batch(DwBatch& b, const float* G, const float* save, const fl
   for (int l = 1; l <= 7; ++l)                                                                          // layers 1..7 (layer 4: hidden columns)
     add(Gt(l), 256, St(l - 1), 256, 256, D(2 * l), l == 4 ? WIDTH + POINT_DIM : WIDTH, 0, D(2 * l + 1), 1.0f);
   add(Gt(4), 256, St(S_GP), 64, POINT_DIM, D(8), WIDTH + POINT_DIM, WIDTH, nullptr, 0.25f);            // layer 4, skip columns
-  add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI), 1.0f);                               // point_info
+  DwItem& pi = add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI), 1.0f);                  // point_info ...
+  pi.has_sig = 1; pi.sig = dz4 ? dz4 + 3 : nullptr; pi.dW2 = D(W_SIGMA);                                // ... + the sigma head (same X = h7)
   add(Gt(G_D), 128, St(S_FEAT), 256, 256, D(W_DIR), WIDTH + DIR_DIM, DIR_DIM, D(B_DIR), 0.5f);         // dir_info, feature columns
-  DwItem& th = add(dz4, 32, St(7), 384, 384, D(W_COLOR), HALF, 0, D(B_COLOR), 0.35f);                  // colour + sigma heads: X = [h7 | c]
-  th.thin = 1; th.X2 = St(S_C); th.dW2 = D(W_SIGMA); th.db2 = D(B_SIGMA);
+  DwItem& th = add(dz4, 32, St(S_C), 128, 128, D(W_COLOR), HALF, 0, D(B_COLOR), 0.1f);                 // colour head (X = c) + the bias gradients of both heads
+  th.thin = 1; th.db2 = D(B_SIGMA);
   // Every product gets ALL DW_WGS workgroups in a launch of its own.  (One launch for all products, the CUs dealt out in
   // proportion to `units`, was built and measured: no gain (8.2 vs 8.1 ms for the phase).  See DESIGN.md section 4b.)
   (void)units;

@@ -132,7 +132,10 @@ __device__ __forceinline__ void dw_rows(const bool BARRIER, const bool BIAS, con
 // time and leaves its partner latency-bound).  Here a SIMD has ONE wave, which hides the memory
 // latency itself: a ring of DW4_DEPTH k-steps (one 16-byte load per operand and k-step), DW4_DEPTH - 1 of them (7 x 1024 MFMA
 // cycles = 3 us) requested ahead of the one being multiplied.  Per k-step: 2 vector-memory instructions for 16 (8) MFMAs.
-constexpr int DW4_DEPTH = 8;
+#ifndef DW4_DEPTH_V
+#define DW4_DEPTH_V 8
+#endif
+constexpr int DW4_DEPTH = DW4_DEPTH_V;
 
 template <int NCB> struct DwVecB;
 template <> struct DwVecB<4> { typedef float4 type; };
@@ -142,14 +145,19 @@ template <int NCB>
 struct DwFrag {
   float4 a;
   typename DwVecB<NCB>::type b;
+  float sg;  // DW_SIG only: dsigma_pre of the lane's row
 };
 
-// rows [r_begin, r_end) (wave-uniform, a multiple of 2 DW4_DEPTH rows long unless CHECK).  gbase / xbase: wave-uniform
-// operand pointers at row 0; goff / xoff: this lane's byte offset inside a row pair (row h, column group q), so that a load
-// is `global_load v, v_off, s[base]` with the row advance in scalar registers.
-template <int NCB, bool BIAS>
-__device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const float* __restrict__ xbase, const unsigned goff, const unsigned xoff,
-                                          const int r_begin, const int r_end, f32x16 (&acc)[4][NCB], float (&bsum)[4]) {
+// what a wave does besides its block (one extra duty per wave at most, so that the four waves of a workgroup stay level):
+constexpr int DW_PLAIN = 0, DW_BIAS = 1, DW_SIG = 2;
+// DW_BIAS  column sums of its 128 columns of G = bias gradient (4 adds per k-step)
+// DW_SIG   sigma head: wsig[col] += dsigma_pre[row] * X[row][col] for its 32 NCB columns of X (one more 4-byte load and 4 FMAs per k-step)
+
+// rows [r_begin, r_end) (wave-uniform, a multiple of 2 DW4_DEPTH rows long).  gbase / xbase / sbase: wave-uniform operand
+// pointers at row 0; goff / xoff / soff: this lane's byte offset inside a row pair (row h, column group q).
+template <int NCB, int DUTY>
+__device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const float* __restrict__ xbase, const float* __restrict__ sbase, const unsigned goff,
+                                          const unsigned xoff, const unsigned soff, const int r_begin, const int r_end, f32x16 (&acc)[4][NCB], float (&bsum)[4]) {
   typedef typename DwVecB<NCB>::type VB;
   constexpr int D = DW4_DEPTH;
   DwFrag<NCB> s[D];
@@ -160,23 +168,24 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
     const char* xa = reinterpret_cast<const char*>(xbase + (size_t)r * WIDTH);
     S.a = *reinterpret_cast<const float4*>(ga + goff);
     S.b = *reinterpret_cast<const VB*>(xa + xoff);
+    if (DUTY == DW_SIG) S.sg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase + (size_t)r * 4) + soff);
   };
   auto mul = [&](const DwFrag<NCB>& S) {
 #pragma unroll
     for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        float bv;
-        if constexpr (NCB == 4) bv = comp(S.b, cb); else bv = comp(S.b, cb);
-        acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(S.a, ca), bv, acc[ca][cb], 0, 0, 0);
-      }
-    if (BIAS) {
-      // as asm statements: plain adds get re-associated across the ring, the stage loads follow them, and the loop ends up
-      // requesting all eight stages at once
+      for (int cb = 0; cb < NCB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(S.a, ca), comp(S.b, cb), acc[ca][cb], 0, 0, 0);
+    // the duties as asm statements: plain adds get re-associated across the ring, the stage loads follow them, and the loop
+    // ends up requesting all eight stages at once
+    if (DUTY == DW_BIAS) {
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[0]) : "v"(S.a.x));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[1]) : "v"(S.a.y));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[2]) : "v"(S.a.z));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[3]) : "v"(S.a.w));
+    }
+    if (DUTY == DW_SIG) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(bsum[cb]) : "v"(S.sg), "v"(comp(S.b, cb)));
     }
   };
   static_for<D - 1>([&](auto I) {  // in ring order (left alone the scheduler issues them last to first, and the loop's first wait drains the ring)
@@ -196,20 +205,27 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
 
 // ragged tail of a pass (a few waves of a launch): one row pair at a time, rows clamped per lane, rows past the end contribute 0
 template <int NCB>
-__device__ __forceinline__ void dw_stream_tail(const float* __restrict__ gbase, const float* __restrict__ xbase, const unsigned goff, const unsigned xoff,
-                                               const int h, const int r_begin, const int r_end, const bool do_bias, f32x16 (&acc)[4][NCB], float (&bsum)[4]) {
+__device__ __forceinline__ void dw_stream_tail(const float* __restrict__ gbase, const float* __restrict__ xbase, const float* __restrict__ sbase, const unsigned goff,
+                                               const unsigned xoff, const unsigned soff, const int h, const int r_begin, const int r_end, const int duty,
+                                               f32x16 (&acc)[4][NCB], float (&bsum)[4]) {
   typedef typename DwVecB<NCB>::type VB;
   for (int r0 = r_begin; r0 < r_end; r0 += 2) {
     const bool live = r0 + h < r_end;
     const int r = live ? r0 : r_end - 1 - h;  // (row r + h of the lane's offsets = r_end - 1)
     float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gbase + (size_t)r * WIDTH) + goff);
     const VB b = *reinterpret_cast<const VB*>(reinterpret_cast<const char*>(xbase + (size_t)r * WIDTH) + xoff);
+    float sg = 0.f;
+    if (duty == DW_SIG && live) sg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase + (size_t)r * 4) + soff);
     if (!live) a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(b, cb), acc[ca][cb], 0, 0, 0);
-    if (do_bias) { bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w; }
+    if (duty == DW_BIAS) { bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w; }
+    if (duty == DW_SIG) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bsum[cb] = __builtin_fmaf(sg, comp(b, cb), bsum[cb]);
+    }
   }
 }
 
@@ -218,27 +234,36 @@ __device__ __forceinline__ void dw_stream_tail(const float* __restrict__ gbase, 
 // geometry of one product, shared by the kernels, the reduce and the host
 __host__ __device__ inline int dwi_ncb(const DwItem& p) { return p.thin ? 2 : (p.nin % 128 == 0 ? 4 : 2); }  // 32-column tiles of X per wave
 __host__ __device__ inline int dwi_waves(const DwItem& p) { return p.thin ? DW_WAVES : 4; }
-__host__ __device__ inline int dwi_in_blocks(const DwItem& p) { return p.thin ? 6 : p.nin / (32 * dwi_ncb(p)); }
-__host__ __device__ inline int dwi_nblocks(const DwItem& p) { return p.thin ? 6 : (p.nout / 128) * dwi_in_blocks(p); }  // 4, 2 (thin: 6 of 8 waves)
-__host__ __device__ inline int dwi_msubs(const DwItem& p) { return p.thin ? 1 : dwi_waves(p) / dwi_nblocks(p); }
+__host__ __device__ inline int dwi_in_blocks(const DwItem& p) { return p.nin / (32 * dwi_ncb(p)); }
+__host__ __device__ inline int dwi_nblocks(const DwItem& p) { return p.thin ? dwi_in_blocks(p) : (p.nout / 128) * dwi_in_blocks(p); }  // 4, 2 (thin: 2)
+__host__ __device__ inline int dwi_msubs(const DwItem& p) { return dwi_waves(p) / dwi_nblocks(p); }
 __host__ __device__ inline size_t dwi_wave_floats(const DwItem& p) { return (size_t)(p.thin ? 1 : 4) * dwi_ncb(p) * 16 * 64; }
-// per workgroup: one block per wave + 128 column sums per wave
-__host__ __device__ inline size_t dwi_wg_floats(const DwItem& p) { return dwi_waves(p) * (dwi_wave_floats(p) + 128); }
+// per workgroup: one block per wave, 128 column sums per wave, and (has_sig) 128 sigma-head sums per wave
+__host__ __device__ inline size_t dwi_wg_floats(const DwItem& p) { return dwi_waves(p) * (dwi_wave_floats(p) + 128 + (p.has_sig ? 128 : 0)); }
+// the extra duty of the wave that holds block (bi, bj) = (128 columns of G, 32 NCB columns of X); thin: the waves of X block 0 sum A
+__host__ __device__ inline int dwi_duty(const DwItem& p, int bi, int bj) {
+  const int in_blocks = dwi_in_blocks(p);
+  if (p.thin) return bj == 0 ? 1 : 0;
+  if (p.db && bj == (bi + 1) % in_blocks) return 1;  // DW_BIAS
+  if (p.has_sig && bj == bi) return 2;               // DW_SIG (needs in_blocks == out blocks: the 256 x 256 point_info product)
+  return 0;
+}
 
-// The thin heads as one product: A = the [rows][4] buffer, one 32-row output tile per wave, X = [h7 | c] in six 64-column blocks
-// (waves 6, 7 idle), every workgroup on 1/nwg of the rows.
+// The colour head as one thin product: A = the [rows][4] buffer (dz_r, dz_g, dz_b, dsigma_pre), one 32-row output tile per wave,
+// X = c in two 64-column blocks x four row sub-ranges; rows 0..2 of the result are dW_color, the column sums of A (waves of
+// block 0) the bias gradients of both heads.  (The sigma head's weights ride on the point_info product, which reads h7 anyway.)
 __global__ __launch_bounds__(512, 2) void k_dw_thin(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
   const int tid = threadIdx.x, lane = tid & 63, lw = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform values stay in SGPRs from here on
-  constexpr int nblocks = 6;
-  if (wv >= nblocks) return;
-  const int blk = wv;
-  const int gran = DW_ROWS * DW_STAGES;
+  constexpr int nblocks = 2, msubs = DW_WAVES / nblocks;
+  const int blk = wv % nblocks, msub = wv / nblocks;
+  const int gran = DW_ROWS * DW_STAGES * msubs;
   const int Mrows = (int)Mtot;  // < 2^31 rows and < 4 GiB per operand (checked by the host)
-  const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran;  // a multiple of the 24 rows of one pipeline round
-  const long long r_begin64 = (long long)lw * per_wg;
+  const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran;
+  const int per_wave = per_wg / msubs;  // a multiple of the 24 rows of one pipeline round
+  const long long r_begin64 = (long long)lw * per_wg + (long long)msub * per_wave;
   const int r_begin = r_begin64 < Mrows ? (int)r_begin64 : Mrows;
-  const long long r_nom = r_begin64 + per_wg;
+  const long long r_nom = r_begin64 + per_wave;
   const int r_end = r_nom > Mrows ? Mrows : (int)r_nom;
   const int h = lane >> 5, q = lane & 31;
 
@@ -250,11 +275,13 @@ __global__ __launch_bounds__(512, 2) void k_dw_thin(const DwItem p, const long l
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   const float* gp = p.G + (q & 3);  // [rows][4]
-  const float* xp = (blk < 4 ? p.X + blk * 64 : p.X2 + (blk - 4) * 64) + 2 * q;
+  const float* xp = p.X + blk * 64 + 2 * q;
   const bool do_bias = blk == 0;  // wave-uniform: column sums of A on this wave
   const bool a_live = q < 4;
-  if (r_nom <= Mrows) dw_rows<1, false>(false, do_bias, gp, xp, 4, r_begin, r_end, h, a_live, acc, bsum);
-  else if (r_begin < r_end) dw_rows<1, true>(false, do_bias, gp, xp, 4, r_begin, r_end, h, a_live, acc, bsum);
+  if (r_begin < r_end) {
+    if (r_nom <= Mrows) dw_rows<1, false>(false, do_bias, gp, xp, 4, r_begin, r_end, h, a_live, acc, bsum);
+    else dw_rows<1, true>(false, do_bias, gp, xp, 4, r_begin, r_end, h, a_live, acc, bsum);
+  }
   // this wave's slab block and its column sums (entry 4q: column sum of A column q; zeros where it did not sum)
   float* wg = slabs + p.slab_off + (size_t)lw * dwi_wg_floats(p);
   float* ws = wg + (size_t)wv * dwi_wave_floats(p);
@@ -301,28 +328,32 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
       for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-  const float* gbase = p.G + (blk / in_blocks) * 128;
-  const float* xbase = p.X + (blk % in_blocks) * (32 * NCB);
-  const unsigned goff = (unsigned)(h * WIDTH + 4 * q) * 4u, xoff = (unsigned)(h * WIDTH + NCB * q) * 4u;
-  // column sums of G = bias gradient: the wave of input block 0 does them for its 128 columns of G (4 adds per k-step)
-  const bool do_bias = p.db != nullptr && (blk % in_blocks) == 0;
+  const int bi = blk / in_blocks, bj = blk % in_blocks;
+  const float* gbase = p.G + bi * 128;
+  const float* xbase = p.X + bj * (32 * NCB);
+  const float* sbase = p.sig;
+  const unsigned goff = (unsigned)(h * WIDTH + 4 * q) * 4u, xoff = (unsigned)(h * WIDTH + NCB * q) * 4u, soff = (unsigned)h * 16u;
+  const int duty = dwi_duty(p, bi, bj);  // wave-uniform
   if (r_begin < r_end) {
     if (r_nom <= Mrows) {
-      // (the empty asm statements differ on purpose: identical starts of the two branches get hoisted into this block, and the
-      // summing variant's loop then waits for the whole ring at every k-step)
-      if (do_bias) {
+      // (the empty asm statements differ on purpose: identical starts of the branches get hoisted into this block, and the
+      // loops then wait for the whole ring at every k-step)
+      if (duty == DW_BIAS) {
         asm volatile("; column sums" ::: "memory");
-        dw_stream<NCB, true>(gbase, xbase, goff, xoff, r_begin, r_end, acc, bsum);
+        dw_stream<NCB, DW_BIAS>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
+      } else if (NCB == 4 && duty == DW_SIG) {
+        asm volatile("; sigma head" ::: "memory");
+        dw_stream<NCB, NCB == 4 ? DW_SIG : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
       } else {
-        asm volatile("; no column sums" ::: "memory");
-        dw_stream<NCB, false>(gbase, xbase, goff, xoff, r_begin, r_end, acc, bsum);
+        asm volatile("; no duty" ::: "memory");
+        dw_stream<NCB, DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
       }
     } else {
-      dw_stream_tail<NCB>(gbase, xbase, goff, xoff, h, r_begin, r_end, do_bias, acc, bsum);
+      dw_stream_tail<NCB>(gbase, xbase, sbase, goff, xoff, soff, h, r_begin, r_end, duty, acc, bsum);
     }
   }
   constexpr size_t wave_floats = (size_t)4 * NCB * 16 * 64;
-  float* wg = slabs + p.slab_off + (size_t)lw * (4 * (wave_floats + 128));
+  float* wg = slabs + p.slab_off + (size_t)lw * dwi_wg_floats(p);
   float* ws = wg + (size_t)wv * wave_floats;
 #pragma unroll
   for (int ca = 0; ca < 4; ++ca)
@@ -330,12 +361,19 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ws[((size_t)(ca * NCB + cb) * 16 + r) * 64 + lane] = acc[ca][cb][r];
+  // the duty's sums: 4 columns per lane (bias: columns 4q.. of the G block; sigma head: columns NCB q.. of the X block), rows h, h + 2, ...
 #pragma unroll
   for (int c = 0; c < 4; ++c) bsum[c] += __shfl_xor(bsum[c], 32);
   if (h == 0) {
     float* bs = wg + 4 * wave_floats + (size_t)wv * 128;
+    float* sg = wg + 4 * (wave_floats + 128) + (size_t)wv * 128;
+    const bool is_sig = duty == DW_SIG;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bs[4 * q + c] = bsum[c];
+    for (int c = 0; c < 4; ++c) bs[4 * q + c] = is_sig ? 0.f : bsum[c];
+    if (p.has_sig) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sg[4 * q + c] = is_sig ? bsum[c] : 0.f;
+    }
   }
 #ifdef NERF_STAMPS
   if (p.stamps && lane == 0) {  // per wave: 100 MHz timestamps, XCC and hardware ids
@@ -358,15 +396,51 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
   const size_t wave_floats = dwi_wave_floats(p), wg_floats = dwi_wg_floats(p);
   const int n_w = nblocks * (int)wave_floats;  // weight elements (padded)
   const int n_b = p.thin ? 4 : (p.db ? p.nout : 0);
+  const int n_s = p.has_sig ? p.nin : 0;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n_w + n_b) return;
+  if (e >= n_w + n_b + n_s) return;
   const float* base = b.slabs + p.slab_off;
+  const int waves = dwi_waves(p);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < n_w) {
     const int blk = e / (int)wave_floats;
     int r = e - blk * (int)wave_floats;
-    for (int ms = 0; ms < msubs; ++ms) {  // fixed order: msub, then workgroup, four partial sums
+    float s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    for (int ms = 0; ms < msubs; ++ms) {  // fixed order: msub, then workgroup, eight partial sums (eight loads in flight per thread)
       const float* q = base + (size_t)(ms * nblocks + blk) * wave_floats + r;
+      int k = 0;
+      for (; k + 8 <= p.nwg; k += 8) {
+        s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
+        s2 += q[(size_t)(k + 2) * wg_floats]; s3 += q[(size_t)(k + 3) * wg_floats];
+        s4 += q[(size_t)(k + 4) * wg_floats]; s5 += q[(size_t)(k + 5) * wg_floats];
+        s6 += q[(size_t)(k + 6) * wg_floats]; s7 += q[(size_t)(k + 7) * wg_floats];
+      }
+      for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
+    }
+    const float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    const int lane = r & 63; r >>= 6;
+    const int reg = r & 15; r >>= 4;
+    const int ncb = dwi_ncb(p);
+    const int cb = r % ncb, ca = r / ncb;
+    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);  // row of the 32 x 32 tile
+    if (p.thin) {
+      const int out = i;                                  // row of A: 0..2 colour (3: dsigma_pre, unused here)
+      const int in = blk * 64 + 2 * (lane & 31) + cb;     // column of c
+      if (out < 3) p.dW[(size_t)out * HALF + in] = s;     // dW_color[3][128]
+    } else {
+      const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * 32 * ncb;
+      const int out = oA + 4 * i + ca;
+      const int in = iB + ncb * (lane & 31) + cb;
+      if (in < p.nin_real) p.dW[(size_t)out * p.ldw + p.col0 + in] = s;
+    }
+  } else if (e < n_w + n_b) {
+    const int o = e - n_w;  // column of G (thin: column of A)
+    const float* bs = base + waves * wave_floats;
+    const int ob = p.thin ? 0 : o / 128, oi = p.thin ? 4 * o : o % 128;
+    for (int w = 0; w < waves; ++w) {  // the waves that summed these columns, in wave order
+      const int blk = w % nblocks;
+      if (dwi_duty(p, p.thin ? 0 : blk / in_blocks, blk % in_blocks) != 1 || (!p.thin && blk / in_blocks != ob)) continue;
+      const float* q = bs + (size_t)w * 128 + oi;
       int k = 0;
       for (; k + 4 <= p.nwg; k += 4) {
         s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
@@ -375,43 +449,25 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
       for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
     }
     const float s = (s0 + s1) + (s2 + s3);
-    const int lane = r & 63; r >>= 6;
-    const int reg = r & 15; r >>= 4;
-    const int ncb = dwi_ncb(p);
-    const int cb = r % ncb, ca = r / ncb;
-    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);  // row of the 32 x 32 tile
-    if (p.thin) {
-      const int out = i;                                  // row of A: 0..2 colour, 3 sigma
-      const int in = blk * 64 + 2 * (lane & 31) + cb;     // 0..255: h7 column, 256..383: c column
-      if (in < WIDTH) { if (out == 3) p.dW2[in] = s; }    // dw_sigma[256]
-      else if (out < 3) p.dW[(size_t)out * HALF + (in - WIDTH)] = s;  // dW_color[3][128]
-    } else {
-      const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * 32 * ncb;
-      const int out = oA + 4 * i + ca;
-      const int in = iB + ncb * (lane & 31) + cb;
-      if (in < p.nin_real) p.dW[(size_t)out * p.ldw + p.col0 + in] = s;
-    }
+    if (p.thin) { if (o < 3) p.db[o] = s; else p.db2[0] = s; }  // db_color[3], db_sigma
+    else p.db[o] = s;
   } else {
-    const int o = e - n_w;  // column of G (thin: column of A)
-    const float* bs = base + dwi_waves(p) * wave_floats;
-    if (p.thin) {
-      for (int k = 0; k < p.nwg; ++k) s0 += bs[(size_t)k * wg_floats + 4 * o];
-      const float s = s0;
-      if (o < 3) p.db[o] = s; else p.db2[0] = s;  // db_color[3], db_sigma
-    } else {
-      const int ob = o / 128, oi = o % 128;
-      for (int w = 0; w < dwi_waves(p); ++w) {
-        if (((w % nblocks) / in_blocks) != ob || ((w % nblocks) % in_blocks) != 0) continue;  // the waves that summed these G columns
-        const float* q = bs + (size_t)w * 128 + oi;
-        int k = 0;
-        for (; k + 4 <= p.nwg; k += 4) {
-          s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
-          s2 += q[(size_t)(k + 2) * wg_floats]; s3 += q[(size_t)(k + 3) * wg_floats];
-        }
-        for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
+    const int o = e - n_w - n_b;  // column of X: sigma-head weight gradient
+    const int ncb = dwi_ncb(p);
+    const int bj = o / (32 * ncb), oi = o % (32 * ncb);
+    const float* sg = base + waves * (wave_floats + 128);
+    for (int w = 0; w < waves; ++w) {
+      const int blk = w % nblocks;
+      if (blk % in_blocks != bj || dwi_duty(p, blk / in_blocks, bj) != 2) continue;
+      const float* q = sg + (size_t)w * 128 + oi;
+      int k = 0;
+      for (; k + 4 <= p.nwg; k += 4) {
+        s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
+        s2 += q[(size_t)(k + 2) * wg_floats]; s3 += q[(size_t)(k + 3) * wg_floats];
       }
-      p.db[o] = (s0 + s1) + (s2 + s3);
+      for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
     }
+    p.dW2[o] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -433,7 +489,7 @@ hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st) {
   int most = 0;
   for (int i = 0; i < b.n; ++i) {
     const DwItem& p = b.item[i];
-    const int total = dwi_nblocks(p) * (int)dwi_wave_floats(p) + (p.thin ? 4 : (p.db ? p.nout : 0));
+    const int total = dwi_nblocks(p) * (int)dwi_wave_floats(p) + (p.thin ? 4 : (p.db ? p.nout : 0)) + (p.has_sig ? p.nin : 0);
     most = total > most ? total : most;
   }
   hipLaunchKernelGGL(k_dw_reduce, dim3((most + 255) / 256, b.n), dim3(256), 0, st, b);

@@ -237,17 +237,29 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
 // direction-encoding columns of dir_info (the weight-gradient GEMMs and the thin heads live in dw_f32.hip)
 // ------------------------------------------------------------------------------------------------
 // direction-encoding columns of dir_info: dW_d[o][k<24] = sum_ray gamma_d[ray][k] * sum_{samples of ray} dpre_d[m][o]
-__global__ __launch_bounds__(128) void k_dir_ray_sums(const SmallGradArgs a) {
-  const int ray = blockIdx.x, t = threadIdx.x;
+__global__ __launch_bounds__(512) void k_dir_ray_sums(const SmallGradArgs a) {
+  // one ray per block: thread (part, column); the four parts take every fourth row, four partial sums each (fixed order)
+  __shared__ float part_sum[4][HALF];
+  const int ray = blockIdx.x, t = threadIdx.x & (HALF - 1), part = threadIdx.x >> 7;
   const size_t MS = (size_t)a.MSrows * WIDTH;
   const float* gd = a.G + G_D * MS;
-  float s = 0.f;
   const size_t c0 = (size_t)ray * a.Nc, f0 = (size_t)a.B * a.Nc + (size_t)ray * a.Nf;
-  for (int i = 0; i < a.Nc; ++i) s += gd[(c0 + i) * WIDTH + t];
-  for (int i = 0; i < a.Nf; ++i) s += gd[(f0 + i) * WIDTH + t];
-  a.sbuf[(size_t)ray * HALF + t] = s;
-  if (t < 12) {
-    const int c = t >> 2, l = t & 3;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  auto span = [&](size_t r0, int n) {
+    int i = part;
+    for (; i + 12 < n; i += 16) {
+      s0 += gd[(r0 + i) * WIDTH + t]; s1 += gd[(r0 + i + 4) * WIDTH + t];
+      s2 += gd[(r0 + i + 8) * WIDTH + t]; s3 += gd[(r0 + i + 12) * WIDTH + t];
+    }
+    for (; i < n; i += 4) s0 += gd[(r0 + i) * WIDTH + t];
+  };
+  span(c0, a.Nc);
+  span(f0, a.Nf);
+  part_sum[part][t] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part == 0) a.sbuf[(size_t)ray * HALF + t] = (part_sum[0][t] + part_sum[1][t]) + (part_sum[2][t] + part_sum[3][t]);
+  if (threadIdx.x < 12) {
+    const int c = threadIdx.x >> 2, l = threadIdx.x & 3;
     const float ph = a.rayf[(size_t)ray * RAYF + RF_DWRD + c] * __uint_as_float(kFreqDirBits[l]);
     a.gdbuf[(size_t)ray * DIR_DIM + c * 8 + 2 * l] = sinf(ph);
     a.gdbuf[(size_t)ray * DIR_DIM + c * 8 + 2 * l + 1] = cosf(ph);
@@ -285,7 +297,7 @@ hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st) {
 }
 
 hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_dir_ray_sums, dim3(a.B), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(k_dir_ray_sums, dim3(a.B), dim3(512), 0, st, a);
   hipLaunchKernelGGL(k_dir_gamma_zero, dim3(1), dim3(128), 0, st, a);
   hipLaunchKernelGGL(k_dir_gamma_dw, dim3(DIR_DIM, DG_CHUNKS), dim3(128), 0, st, a);
   return hipGetLastError();

@@ -151,14 +151,16 @@ struct FieldBwdArgs {
 // One weight-gradient product dW = G^T X of the fp32 train step (dw_f32.hip).
 struct DwItem {
   const float* G;          // [Mtot][256] pre-activation gradients, columns [0, nout)   (thin: the [Mtot][4] buffer dz_r, dz_g, dz_b, dsigma_pre)
-  const float* X;          // [Mtot][256] layer inputs, columns [0, nin)                 (thin: h7)
-  const float* X2;         // thin only: c (128 columns)
+  const float* X;          // [Mtot][256] layer inputs, columns [0, nin)                 (thin: c, 128 columns)
+  const float* sig;        // has_sig: dsigma_pre, one float per row with a stride of 4 (column 3 of the [Mtot][4] buffer)
   int nout, nin;           // 256 / 128 output columns, 256 / 64 (padded) input columns
   int nin_real;            // input columns that exist in dW (60 of 64 for gamma_p)
   float* dW; int ldw, col0;  // destination [nout][ldw], columns col0 .. col0 + nin_real      (thin: dW_color[3][128])
   float* db;               // [nout] bias gradient = column sums of G, or null                 (thin: db_color[3])
-  float* dW2; float* db2;  // thin only: dw_sigma[256], db_sigma[1]
-  int thin;                // 1: the colour + sigma heads as one product
+  float* dW2;              // has_sig: dw_sigma[nin] = sum_m sig[m] * X[m][:]
+  float* db2;              // thin only: db_sigma[1]
+  int thin;                // 1: the colour head (and both heads' bias gradients) as one thin product
+  int has_sig;             // 1: the sigma head rides on this product (X = h7): dW2 from the waves that hold X's columns
   int wg0, nwg;            // workgroups [wg0, wg0 + nwg) of the launch work on this product, each on 1/nwg of the rows
   long long slab_off;      // floats: this product's slabs inside DwBatch::slabs
   unsigned long long* stamps;  // diagnostic build only: per-wave (start, end, xcc, hw id) records
