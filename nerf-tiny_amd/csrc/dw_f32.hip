@@ -240,6 +240,15 @@ __host__ __device__ inline int dwi_msubs(const DwItem& p) { return dwi_waves(p) 
 __host__ __device__ inline size_t dwi_wave_floats(const DwItem& p) { return (size_t)(p.thin ? 1 : 4) * dwi_ncb(p) * 16 * 64; }
 // per workgroup: one block per wave, 128 column sums per wave, and (has_sig) 128 sigma-head sums per wave
 __host__ __device__ inline size_t dwi_wg_floats(const DwItem& p) { return dwi_waves(p) * (dwi_wave_floats(p) + 128 + (p.has_sig ? 128 : 0)); }
+// Slab layout of one product (floats from slab_off): first the accumulator rows -- row = 64 consecutive floats of one wave's
+// block (wave, tile, register) -- stored [workgroup][row][64]: every workgroup writes one contiguous run (the transposed order,
+// [row][workgroup][64], lets the reduce read contiguously but costs the products more than it saves: their 256 stores per wave
+// then lie 64 KiB apart) -- then per workgroup the waves' column sums ([wave][128], and [wave][128] more for the sigma head).
+__host__ __device__ inline size_t dwi_rows_per_wg(const DwItem& p) { return dwi_waves(p) * dwi_wave_floats(p) / 64; }
+__host__ __device__ inline size_t dwi_row_off(const DwItem& p, size_t row, int lw) { return ((size_t)lw * dwi_rows_per_wg(p) + row) * 64; }
+__host__ __device__ inline size_t dwi_wg_stride(const DwItem& p) { return dwi_rows_per_wg(p) * 64; }  // floats between two workgroups' copies of a row
+__host__ __device__ inline size_t dwi_sums_per_wg(const DwItem& p) { return (size_t)dwi_waves(p) * (128 + (p.has_sig ? 128 : 0)); }
+__host__ __device__ inline size_t dwi_sums_off(const DwItem& p, int lw) { return (size_t)p.nwg * dwi_waves(p) * dwi_wave_floats(p) + (size_t)lw * dwi_sums_per_wg(p); }
 // the extra duty of the wave that holds block (bi, bj) = (128 columns of G, 32 NCB columns of X); thin: the waves of X block 0 sum A
 __host__ __device__ inline int dwi_duty(const DwItem& p, int bi, int bj) {
   const int in_blocks = dwi_in_blocks(p);
@@ -282,16 +291,16 @@ __global__ __launch_bounds__(512, 2) void k_dw_thin(const DwItem p, const long l
     if (r_nom <= Mrows) dw_rows<1, false>(false, do_bias, gp, xp, 4, r_begin, r_end, h, a_live, acc, bsum);
     else dw_rows<1, true>(false, do_bias, gp, xp, 4, r_begin, r_end, h, a_live, acc, bsum);
   }
-  // this wave's slab block and its column sums (entry 4q: column sum of A column q; zeros where it did not sum)
-  float* wg = slabs + p.slab_off + (size_t)lw * dwi_wg_floats(p);
-  float* ws = wg + (size_t)wv * dwi_wave_floats(p);
+  // this wave's slab rows and its column sums (entry 4q: column sum of A column q; zeros where it did not sum)
+  float* sl = slabs + p.slab_off;
+  const size_t row0 = (size_t)wv * (dwi_wave_floats(p) / 64);
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ws[((size_t)cb * 16 + r) * 64 + lane] = acc[0][cb][r];
+    for (int r = 0; r < 16; ++r) sl[dwi_row_off(p, row0 + cb * 16 + r, lw) + lane] = acc[0][cb][r];
   bsum[0] += __shfl_xor(bsum[0], 32);
   if (h == 0) {
-    float* bs = wg + DW_WAVES * dwi_wave_floats(p) + (size_t)wv * 128;
+    float* bs = sl + dwi_sums_off(p, lw) + (size_t)wv * 128;
 #pragma unroll
     for (int c = 0; c < 4; ++c) bs[4 * q + c] = (c == 0 && q < 4) ? bsum[0] : 0.f;
   }
@@ -352,21 +361,20 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
       dw_stream_tail<NCB>(gbase, xbase, sbase, goff, xoff, soff, h, r_begin, r_end, duty, acc, bsum);
     }
   }
-  constexpr size_t wave_floats = (size_t)4 * NCB * 16 * 64;
-  float* wg = slabs + p.slab_off + (size_t)lw * dwi_wg_floats(p);
-  float* ws = wg + (size_t)wv * wave_floats;
+  constexpr size_t wave_rows = (size_t)4 * NCB * 16;
+  float* sl = slabs + p.slab_off;
 #pragma unroll
   for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ws[((size_t)(ca * NCB + cb) * 16 + r) * 64 + lane] = acc[ca][cb][r];
+      for (int r = 0; r < 16; ++r) sl[dwi_row_off(p, (size_t)wv * wave_rows + (size_t)(ca * NCB + cb) * 16 + r, lw) + lane] = acc[ca][cb][r];
   // the duty's sums: 4 columns per lane (bias: columns 4q.. of the G block; sigma head: columns NCB q.. of the X block), rows h, h + 2, ...
 #pragma unroll
   for (int c = 0; c < 4; ++c) bsum[c] += __shfl_xor(bsum[c], 32);
   if (h == 0) {
-    float* bs = wg + 4 * wave_floats + (size_t)wv * 128;
-    float* sg = wg + 4 * (wave_floats + 128) + (size_t)wv * 128;
+    float* bs = sl + dwi_sums_off(p, lw) + (size_t)wv * 128;
+    float* sg = bs + 4 * 128;
     const bool is_sig = duty == DW_SIG;
 #pragma unroll
     for (int c = 0; c < 4; ++c) bs[4 * q + c] = is_sig ? 0.f : bsum[c];
@@ -390,84 +398,107 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
 // other loops share its kernel).  A single launch for all big products, the CUs dealt out in proportion to their MFMA time,
 // was also built and measured in round 2: no gain.
 // Sums the slabs of every product of the step and scatters into the nn.Linear-layout gradients: grid (blocks, items).
+// Weight blocks: 256 consecutive slab elements per block, thread = (4 consecutive elements, a quarter of the slabs) with four
+// 16-byte loads in flight, the quarters combined through LDS in a fixed order (deterministic, no float atomics).  The blocks
+// behind them do the column sums (bias gradients, sigma-head weights), one element per thread.
 __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
+  __shared__ float4 part[3][64];
   const DwItem& p = b.item[blockIdx.y];
   const int nblocks = dwi_nblocks(p), msubs = dwi_msubs(p), in_blocks = dwi_in_blocks(p);
-  const size_t wave_floats = dwi_wave_floats(p), wg_floats = dwi_wg_floats(p);
-  const int n_w = nblocks * (int)wave_floats;  // weight elements (padded)
+  const size_t wave_floats = dwi_wave_floats(p);
+  const int n_w = nblocks * (int)wave_floats;  // weight elements (padded), a multiple of 256
   const int n_b = p.thin ? 4 : (p.db ? p.nout : 0);
   const int n_s = p.has_sig ? p.nin : 0;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n_w + n_b + n_s) return;
+  const int wblocks = n_w / 256;
   const float* base = b.slabs + p.slab_off;
   const int waves = dwi_waves(p);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (e < n_w) {
+  if ((int)blockIdx.x < wblocks) {
+    const int quad = threadIdx.x & 63, kp = threadIdx.x >> 6;
+    const int e = ((int)blockIdx.x * 64 + quad) * 4;
     const int blk = e / (int)wave_floats;
     int r = e - blk * (int)wave_floats;
-    float s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-    for (int ms = 0; ms < msubs; ++ms) {  // fixed order: msub, then workgroup, eight partial sums (eight loads in flight per thread)
-      const float* q = base + (size_t)(ms * nblocks + blk) * wave_floats + r;
-      int k = 0;
-      for (; k + 8 <= p.nwg; k += 8) {
-        s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
-        s2 += q[(size_t)(k + 2) * wg_floats]; s3 += q[(size_t)(k + 3) * wg_floats];
-        s4 += q[(size_t)(k + 4) * wg_floats]; s5 += q[(size_t)(k + 5) * wg_floats];
-        s6 += q[(size_t)(k + 6) * wg_floats]; s7 += q[(size_t)(k + 7) * wg_floats];
+    auto add4 = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
+    const int kq = p.nwg / 4, k0 = kp * kq, k1 = kp == 3 ? p.nwg : k0 + kq;
+    const int lane0 = r & 63;
+    const size_t wgs = dwi_wg_stride(p);
+    for (int ms = 0; ms < msubs; ++ms) {  // fixed order: msub, then workgroup, four partial sums
+      const size_t row = ((size_t)(ms * nblocks + blk) * wave_floats + r) / 64;
+      const float* q = base + dwi_row_off(p, row, 0) + lane0;
+      int k = k0;
+      for (; k + 4 <= k1; k += 4) {
+        add4(t0, *reinterpret_cast<const float4*>(q + (size_t)k * wgs));
+        add4(t1, *reinterpret_cast<const float4*>(q + (size_t)(k + 1) * wgs));
+        add4(t2, *reinterpret_cast<const float4*>(q + (size_t)(k + 2) * wgs));
+        add4(t3, *reinterpret_cast<const float4*>(q + (size_t)(k + 3) * wgs));
       }
-      for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
+      for (; k < k1; ++k) add4(t0, *reinterpret_cast<const float4*>(q + (size_t)k * wgs));
     }
-    const float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-    const int lane = r & 63; r >>= 6;
+    add4(t0, t1); add4(t2, t3); add4(t0, t2);
+    if (kp) part[kp - 1][quad] = t0;
+    __syncthreads();
+    if (kp) return;
+    add4(t0, part[0][quad]);
+    float4 u = part[1][quad];
+    add4(u, part[2][quad]);
+    add4(t0, u);
+    const float sv[4] = {t0.x, t0.y, t0.z, t0.w};
+    r >>= 6;
     const int reg = r & 15; r >>= 4;
     const int ncb = dwi_ncb(p);
     const int cb = r % ncb, ca = r / ncb;
-    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);  // row of the 32 x 32 tile
-    if (p.thin) {
-      const int out = i;                                  // row of A: 0..2 colour (3: dsigma_pre, unused here)
-      const int in = blk * 64 + 2 * (lane & 31) + cb;     // column of c
-      if (out < 3) p.dW[(size_t)out * HALF + in] = s;     // dW_color[3][128]
-    } else {
-      const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * 32 * ncb;
-      const int out = oA + 4 * i + ca;
-      const int in = iB + ncb * (lane & 31) + cb;
-      if (in < p.nin_real) p.dW[(size_t)out * p.ldw + p.col0 + in] = s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lane = lane0 + j;
+      const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);  // row of the 32 x 32 tile
+      if (p.thin) {
+        const int out = i;                                   // row of A: 0..2 colour (3: dsigma_pre, unused here)
+        const int in = blk * 64 + 2 * (lane & 31) + cb;      // column of c
+        if (out < 3) p.dW[(size_t)out * HALF + in] = sv[j];  // dW_color[3][128]
+      } else {
+        const int oA = (blk / in_blocks) * 128, iB = (blk % in_blocks) * 32 * ncb;
+        const int out = oA + 4 * i + ca;
+        const int in = iB + ncb * (lane & 31) + cb;
+        if (in < p.nin_real) p.dW[(size_t)out * p.ldw + p.col0 + in] = sv[j];
+      }
     }
-  } else if (e < n_w + n_b) {
-    const int o = e - n_w;  // column of G (thin: column of A)
-    const float* bs = base + waves * wave_floats;
+    return;
+  }
+  // column sums: one wave per column, lane = workgroups k = lane, lane + 64, ...; combined by a fixed shuffle tree
+  const int col = ((int)blockIdx.x - wblocks) * 4 + ((int)threadIdx.x >> 6), kp = (int)threadIdx.x & 63;
+  if (col >= n_b + n_s) return;  // wave-uniform
+  const size_t sums_per_wg = dwi_sums_per_wg(p);
+  float s = 0.f;
+  if (col < n_b) {
+    const int o = col;  // column of G (thin: column of A)
+    const float* bs = base + dwi_sums_off(p, 0);
     const int ob = p.thin ? 0 : o / 128, oi = p.thin ? 4 * o : o % 128;
     for (int w = 0; w < waves; ++w) {  // the waves that summed these columns, in wave order
       const int blk = w % nblocks;
       if (dwi_duty(p, p.thin ? 0 : blk / in_blocks, blk % in_blocks) != 1 || (!p.thin && blk / in_blocks != ob)) continue;
       const float* q = bs + (size_t)w * 128 + oi;
-      int k = 0;
-      for (; k + 4 <= p.nwg; k += 4) {
-        s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
-        s2 += q[(size_t)(k + 2) * wg_floats]; s3 += q[(size_t)(k + 3) * wg_floats];
-      }
-      for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
+      for (int k = kp; k < p.nwg; k += 64) s += q[(size_t)k * sums_per_wg];
     }
-    const float s = (s0 + s1) + (s2 + s3);
-    if (p.thin) { if (o < 3) p.db[o] = s; else p.db2[0] = s; }  // db_color[3], db_sigma
-    else p.db[o] = s;
   } else {
-    const int o = e - n_w - n_b;  // column of X: sigma-head weight gradient
+    const int o = col - n_b;  // column of X: sigma-head weight gradient
     const int ncb = dwi_ncb(p);
     const int bj = o / (32 * ncb), oi = o % (32 * ncb);
-    const float* sg = base + waves * (wave_floats + 128);
+    const float* sg = base + dwi_sums_off(p, 0) + (size_t)waves * 128;
     for (int w = 0; w < waves; ++w) {
       const int blk = w % nblocks;
       if (blk % in_blocks != bj || dwi_duty(p, blk / in_blocks, bj) != 2) continue;
       const float* q = sg + (size_t)w * 128 + oi;
-      int k = 0;
-      for (; k + 4 <= p.nwg; k += 4) {
-        s0 += q[(size_t)k * wg_floats]; s1 += q[(size_t)(k + 1) * wg_floats];
-        s2 += q[(size_t)(k + 2) * wg_floats]; s3 += q[(size_t)(k + 3) * wg_floats];
-      }
-      for (; k < p.nwg; ++k) s0 += q[(size_t)k * wg_floats];
+      for (int k = kp; k < p.nwg; k += 64) s += q[(size_t)k * sums_per_wg];
     }
-    p.dW2[o] = (s0 + s1) + (s2 + s3);
+  }
+#pragma unroll
+  for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+  if (kp) return;
+  if (col < n_b) {
+    if (p.thin) { if (col < 3) p.db[col] = s; else p.db2[0] = s; }  // db_color[3], db_sigma
+    else p.db[col] = s;
+  } else {
+    p.dW2[col - n_b] = s;
   }
 }
 
@@ -489,10 +520,10 @@ hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st) {
   int most = 0;
   for (int i = 0; i < b.n; ++i) {
     const DwItem& p = b.item[i];
-    const int total = dwi_nblocks(p) * (int)dwi_wave_floats(p) + (p.thin ? 4 : (p.db ? p.nout : 0)) + (p.has_sig ? p.nin : 0);
-    most = total > most ? total : most;
+    const int blocks = dwi_nblocks(p) * (int)dwi_wave_floats(p) / 256 + ((p.thin ? 4 : (p.db ? p.nout : 0)) + (p.has_sig ? p.nin : 0) + 3) / 4;
+    most = blocks > most ? blocks : most;
   }
-  hipLaunchKernelGGL(k_dw_reduce, dim3((most + 255) / 256, b.n), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(k_dw_reduce, dim3(most, b.n), dim3(256), 0, st, b);
   return hipGetLastError();
 }
 
