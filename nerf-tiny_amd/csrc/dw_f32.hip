@@ -166,8 +166,10 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
     r = r <= r_last ? r : r_last;  // the prefetches past the end re-read the last row pair (valid memory, never multiplied)
     const char* ga = reinterpret_cast<const char*>(gbase + (size_t)r * WIDTH);
     const char* xa = reinterpret_cast<const char*>(xbase + (size_t)r * WIDTH);
-    S.a = *reinterpret_cast<const float4*>(ga + goff);
-    S.b = *reinterpret_cast<const VB*>(xa + xoff);
+    unsigned go = goff, xo = xoff;
+    asm volatile("" : "+v"(go), "+v"(xo));  // opaque here: otherwise base + lane offset is hoisted as a 64-bit vector and every load pays a 64-bit vector add
+    S.a = *reinterpret_cast<const float4*>(ga + go);
+    S.b = *reinterpret_cast<const VB*>(xa + xo);
     if (DUTY == DW_SIG) S.sg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase + (size_t)r * 4) + soff);
   };
   auto mul = [&](const DwFrag<NCB>& S) {
