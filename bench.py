@@ -299,15 +299,19 @@ def rooflines(leg, prof, b_local, steps):
         flop = FLOP_PER_SAMPLE * b_local * (NC + NF)
         ach = flop / (dw_ms * 1e-3) / 1e12 if dw_ms > 0 else 0.0
         dw = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-              "traffic": read_traffic(["k_dw<4>", "k_dw<1>", "k_dw_reduce"], train=True, scale={"k_dw<4>": 11, "k_dw<1>": 1, "k_dw_reduce": 1}),
-              "traffic_source": "profiles/pmc_train_latest.json (committed rocprofv3 --pmc passes; 11 k_dw<4> + k_dw<1> + k_dw_reduce per step)",
-              "kernel": "k_dw (all weight-gradient products of one step incl. reduces and thin heads = one 'launch')",
+              "traffic": read_traffic(list(DW_LAUNCHES), train=True, scale=DW_LAUNCHES),
+              "traffic_source": "profiles/pmc_train_latest.json (committed rocprofv3 --pmc passes; per step: " + ", ".join(f"{n} x {k}" for k, n in DW_LAUNCHES.items()) + ")",
+              "kernel": "k_dw4 / k_dw_thin / k_dw_reduce / k_dir_* (all weight-gradient products of one step incl. the reduce and the thin colour head = one 'launch')",
               "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "flop_per_launch": flop}
     phases = {"forward_with_saves": fwd, "dx_chain": chain, "dw": dw}
     dominant = max(phases.values(), key=lambda b: b["avg_launch_ms"] * (2 if b is not dw else 1))
     return dominant, phases
 
 
+# launches of the fp32 weight-gradient phase per train step (dw_f32.hip, field_bwd.hip): the 128 x 128-block products (layers 1-7,
+# point_info + sigma head, dir_info), the 128 x 64-block ones (layer 0, layer 4's skip columns), the colour head, the reduce, and the
+# three small kernels of dir_info's direction-encoding columns
+DW_LAUNCHES = {"k_dw4<4>": 9, "k_dw4<2>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_dir_ray_sums": 1, "k_dir_gamma_zero": 1, "k_dir_gamma_dw": 1}
 DW_BF16_KIB_PER_WAVE_BLOCK = 318  # G and X pieces of bf16_common.h over the 11 products
 
 
