@@ -36,6 +36,9 @@ static_assert((size_t)BF_BIAS_BYTES + (size_t)BX_NCHUNK * BF_CHUNK * BF_FRAG_BYT
 // bias block: the float layout of the 32x32x16 image (bf16_common.h), addressed per 16 features
 constexpr int BXB_PI = 32 * BFB_PI, BXB_SIGMA = 32 * BFB_SIGMA, BXB_DIR = 32 * BFB_DIR, BXB_COL = 32 * BFB_COL;
 
+constexpr int BX_LDS_BYTES = BF_LDS_BYTES + BF_WG * 32;  // bias block + ring + 32 bytes per lane of parked encodings = 160 KiB
+static_assert(BX_LDS_BYTES <= 160 * 1024, "LDS of one CU");
+
 struct BxStream {
   static constexpr int NFRAG = BX_NFRAG, NCHUNK = BX_NCHUNK, NS = BF_NS, RING_OFF = BF_BIAS_BYTES, D = BF_D;
   static constexpr bool HAS_BIAS = true;
@@ -157,6 +160,12 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
     }
   }
 
+  // the direction encodings are needed 1,100 fragments later: parked in the 16 KiB of LDS behind the ring (32 bytes per lane)
+  // instead of 8 registers the allocator would spill to scratch
+  u32x4* const gd_park = reinterpret_cast<u32x4*>(lds + BF_LDS_BYTES) + 2 * threadIdx.x;
+  gd_park[0] = gd[0][0];
+  gd_park[1] = gd[1][0];
+
   u32x4 fr[BF_D];
   bf_stream_first<S>(c, fr);
 
@@ -208,18 +217,32 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
   bx_segment<BXS_PI, 16, 8, 0, BXB_PI, 0, BXB_SIGMA>(c, fr, acc, Y, nullptr, pi_epi, last_of(relu_to(Y), 15));
   bx_segment<BXS_PI + 128, 1, 8, 0, BXB_SIGMA, 0, BXB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(pi_epi, 15));
   // ---- dir_info on cat(gamma_d, feat), ReLU (nerf.py:117-118); its first tile also retires the sigma tile
+  {
+    const int lane_d = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));  // (re-derived: no address register kept across the stream)
+    const u32x4* const back = reinterpret_cast<const u32x4*>(lds + BF_LDS_BYTES) + 2 * (c.wv * 64 + lane_d);
+    gd[0][0] = back[0];
+    gd[1][0] = back[1];
+  }
   bx_segment<BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, X, relu_to(Y), last_of(pi_epi, 16));
+  // (sample indices are re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing to keep alive or spill)
+  const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int n_e = lane_e & 15;
+  const bool q0_e = lane_e < 16;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-    if (valid[h] && q == 0) a.sigma[ms[h]] = fabsf(spre[h]);
+  for (int h = 0; h < 2; ++h) {
+    const int me = m0 + 16 * h + n_e;
+    if (me < a.M && q0_e) a.sigma[me] = fabsf(spre[h]);
+  }
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
   bx_segment<BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 7));
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-    if (valid[h] && q == 0) {
+  for (int h = 0; h < 2; ++h) {
+    const int me = m0 + 16 * h + n_e;
+    if (me < a.M && q0_e) {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) a.rgb[(size_t)ms[h] * 3 + ch] = 1.0f / (1.0f + expf(-acc[1].c[h][ch]));
+      for (int ch = 0; ch < 3; ++ch) a.rgb[(size_t)me * 3 + ch] = 1.0f / (1.0f + expf(-acc[1].c[h][ch]));
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -283,9 +306,9 @@ hipError_t launch_pack_weights_bf16x(const Weights24& w, unsigned char* img, hip
 
 hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st) {
   static std::atomic<unsigned long long> opted{0};
-  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16x)}, BF_LDS_BYTES)) return e;
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16x)}, BX_LDS_BYTES)) return e;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
-  hipLaunchKernelGGL(k_field_fwd_bf16x, dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);
+  hipLaunchKernelGGL(k_field_fwd_bf16x, dim3(wgs), dim3(BF_WG), BX_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 
