@@ -131,6 +131,24 @@ def test_chain_and_weight_gradients_on_coarse_only_loss(oracle, pkg, dev, name):
     print(f"{name}: coarse-only loss, worst grad L2-rel {worst:.2e}")
 
 
+@pytest.mark.parametrize("rays", [333, 99, 7])
+def test_weight_gradients_on_ragged_row_counts(oracle, pkg, dev, rays):
+    """Row counts that do not fill the weight-gradient kernels' row ranges: 333 rays = 63,936 rows leave a ragged last range in every
+    product shape (the per-row tail loop with its clamped rows, incl. the column-sum and sigma-head duties), 99 rays in the
+    256 x 256 ones only, 7 rays leave most of the 256 workgroups without rows.  Bar 3e-4 per tensor: layer 0's weight gradient
+    (the ill-conditioned one, see _sensitivity_band) sits at 1.5e-4 for 333 rays in fp32 on either side, while ONE dropped or doubled row
+    of 63,936 would move a gradient by ~1 / sqrt(rows) = 4e-3."""
+    g, inputs, Nc, Nf, w = _case(oracle, "cfg1_lego_crop32", max_rays=rays)
+    assert inputs[0].shape[0] == rays
+    p, st, oloss = _oracle_with_grads(oracle, w, inputs, Nc, Nf, coarse_only=True)
+    m, loss = _train_step(pkg, oracle, dev, w, inputs, Nc, Nf, coarse_only=True)
+    assert abs(float(loss) - float(oloss)) <= 1e-5 * float(oloss)
+    errs = {k: l2_rel(q.grad, ref.grad) for (k, ref), q in zip(p.items(), m.network.parameters())}
+    print(f"{rays} rays: worst grad L2-rel {max(errs.values()):.2e} ({max(errs, key=errs.get)})")
+    for k, e in errs.items():
+        assert e < 3e-4, (k, e)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_merge_backward_given_reference_sort_order(oracle, pkg, dev, name):
     """rows a8/a9 backward: d sigma, d rgb of both passes and the merge part of d t_fine (workspace buffers after
