@@ -52,11 +52,11 @@ int check_sizes(int B, int Nc, int Nf) {
 size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 
 
-// The twelve weight-gradient products of the fp32 train step (dw_f32.hip) with their slab offsets; pointers are filled in
+// The twelve weight-gradient products (eleven MFMA-bound ones, one of them carrying the sigma head, + the thin colour head) of the fp32 train step (dw_f32.hip) with their slab offsets; pointers are filled in
 // by nerf_hip_backward (null here: only sizes matter for the layout).
 long long build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw) {
   memset(&b, 0, sizeof(b));
-  // MFMA time of each product in units of a 256 x 256 one (the thin-heads product is load-bound: measured 0.35)
+  // MFMA time of each product in units of a 256 x 256 one (the thin colour-head product is load-bound)
   float units[DW_MAX_ITEMS];
   auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db, float u) -> DwItem& {
     units[b.n] = u;

@@ -1,15 +1,15 @@
 // dw_f32.hip -- the weight-gradient GEMMs of the fp32 train step for MI355X (gfx950).
 //
-//  k_dw           one launch for every product; per product (dw_item<NCA>): dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32 with the
-//                 SAMPLE as the k index): both operands are read straight from their row-major HBM images (lane (q, h) <-
-//                 columns 4q..4q+3 of G and 2q..2q+1 of X, row m + h), one 128 x 64 output block = 128 accumulators per
-//                 wave, 8 waves (two per SIMD), one workgroup per CU, a branch-free 3-stage register rotation with pinned
-//                 prefetches, per-wave partial slabs.  fp32 MFMA runs on the SIMD's fp32 lanes, so every VALU instruction
-//                 in the loop is MFMA time lost; the bias gradients (column sums of G, four adds per k-step) ride on one of
-//                 the waves that read the same G columns.
-//                 NCA = 1: the thin heads as one product -- A = the [rows][4] buffer (dz_r, dz_g, dz_b, dsigma_pre), one
-//                 32-row output tile per wave, X = [h7 | c]: rows 0..2 x c give the colour head, row 3 x h7 the sigma head,
-//                 the column sums of A their biases.
+//  k_dw4<NCB>     one launch per product: dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM
+//                 (v_mfma_f32_32x32x2_f32 with the SAMPLE as the k index): both operands are read straight from their
+//                 row-major HBM images (lane (q, h) <- columns 4q..4q+3 of G and NCB q.. of X, row m + h).  ONE wave per SIMD:
+//                 a 128 x 32 NCB output block = 64 NCB accumulators per wave, 4 waves = one workgroup per CU on 1/256 of the
+//                 rows, an 8-deep register ring of k-steps (7 requested ahead), per-wave partial slabs.  fp32 MFMA runs on the
+//                 SIMD's fp32 lanes, so every VALU instruction in the loop is MFMA time lost: a wave carries at most one extra
+//                 duty -- the column sums of its G block (bias gradient) or, on the point_info product, the sigma head's weight
+//                 gradient (sum_m dsigma_pre[m] * h7[m][:], same X) -- as asm-pinned adds / FMAs in the same loop.
+//  k_dw_thin      the colour head as one thin product: A = the [rows][4] buffer (dz_r, dz_g, dz_b, dsigma_pre), one 32-row
+//                 output tile per wave, X = c; the column sums of A are the bias gradients of both heads.  HBM-bound.
 //  k_dw_reduce    ONE launch per step: sums the slabs of all products in a fixed order (deterministic, no float atomics)
 //                 and scatters into the nn.Linear-layout gradients.
 //
@@ -36,7 +36,8 @@ struct DwStage {
   float2 b[DW_UNROLL];
 };
 
-// Main loop over rows [r_begin, r_end) (wave-uniform).  CHECK = false: every row of every stage is in range (no selects
+// Main loop of the thin product (the 3-stage rotation of round 1's two-waves-per-SIMD kernel; NCA = 1 is the only instantiation
+// left) over rows [r_begin, r_end) (wave-uniform).  CHECK = false: every row of every stage is in range (no selects
 // between the loads and their use, so the loads of two stages stay in flight behind the MFMAs of the third).  CHECK = true
 // (the ragged tail of a pass only): rows are clamped per lane and rows past the end contribute nothing.
 // gp / xp: this lane's operand pointers at row 0 (column group q; row h is added per stage).
