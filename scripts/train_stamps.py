@@ -35,13 +35,13 @@ show("backward chain, coarse", v[32:39], v[63], ["prologue (colour head)", "dir_
      [0, 512, 1032, 3072, 1024, 3072, 0])
 show("backward chain, fine", v[40:47], v[62], ["prologue (colour head)", "dir_info", "point_info + sigma", "layers 7-5", "layer 4 (+skip)", "layers 3-1", "layer 0 + d t"],
      [0, 512, 1032, 3072, 1280, 3072, 128])
-# k_dw of layer 1 (a 256 x 256 product): per-wave records
-rec = torch.tensor(v[64:64 + 256 * 8 * 4]).view(256, 8, 4)
+# k_dw4 of layer 1 (a 256 x 256 product): per-wave records
+rec = torch.tensor(v[64:64 + 256 * 8 * 4]).view(256, 8, 4)[:, :4]  # k_dw4: four waves per workgroup (record slots 4..7 unused)
 t0 = rec[:, :, 0].min()
 start = (rec[:, :, 0] - t0).float() / 100.0  # us
 end = (rec[:, :, 1] - t0).float() / 100.0
 wg_end = end.max(1).values; wg_start = start.min(1).values
-print(f"k_dw (layer 1, 256 x 256): workgroup start spread {float(wg_start.min()):.1f}..{float(wg_start.max()):.1f} us, end {float(wg_end.min()):.1f}..{float(wg_end.max()):.1f} us, "
+print(f"k_dw4 (layer 1, 256 x 256): workgroup start spread {float(wg_start.min()):.1f}..{float(wg_start.max()):.1f} us, end {float(wg_end.min()):.1f}..{float(wg_end.max()):.1f} us, "
       f"mean end {float(wg_end.mean()):.1f} us")
 xcc = rec[:, 0, 2] & 0xF
 by = collections.defaultdict(list)

@@ -35,3 +35,19 @@ def test_mismatched_world_size_is_refused():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_train_traffic_lookup_matches_the_shipped_kernel_names():
+    """bench.py reads the weight-gradient phase's HBM bytes from the committed PMC summary by kernel name: a renamed kernel
+    (or a summary collected before the rename) would silently turn `roofline.traffic` into null."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.read_traffic(list(bench.DW_LAUNCHES), train=True, scale=bench.DW_LAUNCHES)
+    assert t is not None and 10e9 < t < 40e9, t  # 24.7 GB per step measured (DESIGN.md section 4b)
+    for keys in (["k_field_fwd"], ["k_field_bwd_reg<true>", "k_field_bwd_reg<false>"]):
+        assert bench.read_traffic(keys, train=True) is not None, keys
+    assert bench.read_traffic(["k_field_fwd"]) is not None
