@@ -504,7 +504,7 @@ int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_
       {"rgb_c", L.rgb_c}, {"w_c", L.w_c}, {"t_f", L.t_f}, {"sig_f", L.sig_f}, {"rgb_f", L.rgb_f}, {"perm", L.perm},
       {"w_m", L.w_m}, {"bundle", L.bundle}, {"save", L.save}, {"masks", L.masks}, {"spre", L.spre}, {"G", L.G}, {"dz", L.dz},
       {"dspre", L.dspre}, {"drgb_c", L.drgb_c}, {"dsig_c", L.dsig_c}, {"drgb_f", L.drgb_f}, {"dsig_f", L.dsig_f},
-      {"dt_f", L.dt_f}, {"slabs", L.slabs}, {"masks", L.masks}};
+      {"dt_f", L.dt_f}, {"slabs", L.slabs}, {"masks", L.masks}, {"sbuf", L.sbuf}, {"gdbuf", L.gdbuf}};
   for (auto& e : tab)
     if (strcmp(e.n, name) == 0) {
       if (e.o == 0 && strcmp(name, "status") != 0) return fail(NERF_HIP_ERR_ARG, "buffer %s is not part of this layout (flags=%d)", name, flags);

@@ -3,7 +3,7 @@
 An analytic scene (a shaded sphere in front of a white background, seen by a ring of cameras with the reference's camera
 convention -- rays come from nerf_hip_rays, so quirk Q2 is honoured) is rendered to images; a NeRFRunner trains on the
 training views and is evaluated on held-out views.  Reports PSNR before/after and the trainer's rays/s.
-Usage (GPU box):  python scripts/teacher_student.py [iterations] [bf16]  ->  one JSON line (copied to profiles/ by hand).
+Usage (GPU box):  python scripts/teacher_student.py [iterations] [bf16|f32] [seed]  ->  one JSON line (copied to profiles/ by hand).
 """
 import json
 import os
@@ -26,6 +26,9 @@ def psnr(a, b):
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
     bf16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+    if len(sys.argv) > 3:  # same initial weights (and whatever else draws from torch's default generators) for A/B runs
+        torch.manual_seed(int(sys.argv[3]))
+        torch.cuda.manual_seed_all(int(sys.argv[3]))
     dev = torch.device("cuda:0")
     H = W = 64
     scene = P.data.analytic_sphere_scene(n_pic=24, H=H, W=W, seed=5, device=dev)
