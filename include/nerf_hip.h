@@ -80,7 +80,9 @@ int nerf_hip_ws_bytes(int B, int Nc, int Nf, int flags, size_t* bytes);
  * "t_c" "sig_c" "rgb_c" "w_c" "t_f" "sig_f" "rgb_f", and with NERF_HIP_SAVE_FOR_BACKWARD also "bundle" "w_m" "perm"
  * "save" "G" "dz" "dspre" "drgb_c" "dsig_c" "drgb_f" "dsig_f" "dt_f" (gradient buffers are valid after backward).
  * "save" and "G" are [tensor][B*(Nc+Nf) + 64][256] f32: 64 dump rows follow the real rows of every tensor; "dz" is
- * [B*(Nc+Nf)][4] = (dz_r, dz_g, dz_b, dsigma_pre).  "dbg": 16384 u64 words written only by diagnostic builds (make stamps). */
+ * [B*(Nc+Nf)][4] = (dz_r, dz_g, dz_b, dsigma_pre).  "sbuf" [B][128] = per-ray sums of the dir_info pre-activation gradient,
+ * "gdbuf" [B][24] = the direction encodings (both valid after a fp32 backward).  "dbg": 16384 u64 words written only by
+ * diagnostic builds (make stamps). */
 int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_t* offset);
 
 /*
