@@ -150,8 +150,9 @@ struct DwFrag {
 };
 
 // what a wave does besides its block (one extra duty per wave at most, so that the four waves of a workgroup stay level):
-constexpr int DW_PLAIN = 0, DW_BIAS = 1, DW_SIG = 2;
+constexpr int DW_PLAIN = 0, DW_BIAS = 1, DW_SIG = 2, DW_BIAS_LO = 3, DW_BIAS_HI = 4;
 // DW_BIAS  column sums of its 128 columns of G = bias gradient (4 adds per k-step)
+// DW_BIAS_LO / _HI  the same sums shared by the two waves that read the same G block: columns 4q, 4q+1 / 4q+2, 4q+3 (2 adds per k-step)
 // DW_SIG   sigma head: wsig[col] += dsigma_pre[row] * X[row][col] for its 32 NCB columns of X (one more 4-byte load and 4 FMAs per k-step)
 
 // rows [r_begin, r_end) (wave-uniform, a multiple of 2 DW4_DEPTH rows long).  gbase / xbase / sbase: wave-uniform operand
@@ -190,6 +191,14 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(bsum[cb]) : "v"(S.sg), "v"(comp(S.b, cb)));
     }
+    if (DUTY == DW_BIAS_LO) {
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[0]) : "v"(S.a.x));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[1]) : "v"(S.a.y));
+    }
+    if (DUTY == DW_BIAS_HI) {
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[2]) : "v"(S.a.z));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[3]) : "v"(S.a.w));
+    }
   };
   static_for<D - 1>([&](auto I) {  // in ring order (left alone the scheduler issues them last to first, and the loop's first wait drains the ring)
     load(r_begin + 2 * (int)I, s[I]);
@@ -225,6 +234,8 @@ __device__ __forceinline__ void dw_stream_tail(const float* __restrict__ gbase, 
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(b, cb), acc[ca][cb], 0, 0, 0);
     if (duty == DW_BIAS) { bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w; }
+    if (duty == DW_BIAS_LO) { bsum[0] += a.x; bsum[1] += a.y; }
+    if (duty == DW_BIAS_HI) { bsum[2] += a.z; bsum[3] += a.w; }
     if (duty == DW_SIG) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) bsum[cb] = __builtin_fmaf(sg, comp(b, cb), bsum[cb]);
@@ -256,10 +267,15 @@ __host__ __device__ inline size_t dwi_sums_off(const DwItem& p, int lw) { return
 __host__ __device__ inline int dwi_duty(const DwItem& p, int bi, int bj) {
   const int in_blocks = dwi_in_blocks(p);
   if (p.thin) return bj == 0 ? 1 : 0;
-  if (p.db && bj == (bi + 1) % in_blocks) return 1;  // DW_BIAS
-  if (p.has_sig && bj == bi) return 2;               // DW_SIG (needs in_blocks == out blocks: the 256 x 256 point_info product)
-  return 0;
+  if (p.has_sig) {  // the 256 x 256 point_info product: sigma head on the diagonal waves, column sums on the other two
+    if (bj == bi) return 2;                          // DW_SIG
+    return p.db ? 1 : 0;                             // DW_BIAS
+  }
+  if (!p.db) return 0;
+  if (in_blocks == 2) return bj == 0 ? 3 : 4;        // DW_BIAS_LO / DW_BIAS_HI: half the sums on each of the two waves of a G block
+  return bj == 0 ? 1 : 0;                            // DW_BIAS (one wave per G block)
 }
+__host__ __device__ inline bool dwi_sums_columns(int duty) { return duty == 1 || duty == 3 || duty == 4; }
 
 // The colour head as one thin product: A = the [rows][4] buffer (dz_r, dz_g, dz_b, dsigma_pre), one 32-row output tile per wave,
 // X = c in two 64-column blocks x four row sub-ranges; rows 0..2 of the result are dW_color, the column sums of A (waves of
@@ -353,6 +369,12 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
       if (duty == DW_BIAS) {
         asm volatile("; column sums" ::: "memory");
         dw_stream<NCB, DW_BIAS>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
+      } else if (NCB == 4 && duty == DW_BIAS_LO) {
+        asm volatile("; column sums, low half" ::: "memory");
+        dw_stream<NCB, NCB == 4 ? DW_BIAS_LO : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
+      } else if (NCB == 4 && duty == DW_BIAS_HI) {
+        asm volatile("; column sums, high half" ::: "memory");
+        dw_stream<NCB, NCB == 4 ? DW_BIAS_HI : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
       } else if (NCB == 4 && duty == DW_SIG) {
         asm volatile("; sigma head" ::: "memory");
         dw_stream<NCB, NCB == 4 ? DW_SIG : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
@@ -478,7 +500,7 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
     const int ob = p.thin ? 0 : o / 128, oi = p.thin ? 4 * o : o % 128;
     for (int w = 0; w < waves; ++w) {  // the waves that summed these columns, in wave order
       const int blk = w % nblocks;
-      if (dwi_duty(p, p.thin ? 0 : blk / in_blocks, blk % in_blocks) != 1 || (!p.thin && blk / in_blocks != ob)) continue;
+      if (!dwi_sums_columns(dwi_duty(p, p.thin ? 0 : blk / in_blocks, blk % in_blocks)) || (!p.thin && blk / in_blocks != ob)) continue;
       const float* q = bs + (size_t)w * 128 + oi;
       for (int k = kp; k < p.nwg; k += 64) s += q[(size_t)k * sums_per_wg];
     }
