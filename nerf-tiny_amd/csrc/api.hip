@@ -136,7 +136,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
       L.dz = take(Mtot * 16);
       L.dspre = take(Mtot * 4);
       L.slabs = take(dw_batch_slab_floats() * 4);  // every product of the step keeps its own slabs: ONE reduce launch at the end
-      L.sbuf = take(b * HALF * 4);
+      L.sbuf = take(2 * b * HALF * 4);
       L.gdbuf = take(b * DIR_DIM * 4);
     }
     L.drgb_c = take(b * Nc * 12);
@@ -481,6 +481,15 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
 #ifdef NERF_STAMPS
     batch.item[1].stamps = at<unsigned long long>(ws, L.dbg) + 64;  // layer 1: a 256 x 256 product
 #endif
+    // the dir_info product writes the per-ray sums of its G operand on the way when its row ranges line up with the rays
+    bool ray_duty = false;
+    for (int i = 0; i < batch.n; ++i) {
+      DwItem& p = batch.item[i];
+      if (p.G == G + (size_t)G_D * MS && dw_ray_duty_ok(p, Mtot, B, Nc, Nf)) {
+        p.raysum = at<float>(ws, L.sbuf); p.ray_nc = Nc; p.ray_nf = Nf; p.rows_c = B * Nc;
+        ray_duty = true;
+      }
+    }
     HIP_TRY(launch_dw(batch, Mtot, slabs, st));
     HIP_TRY(launch_dw_reduce(batch, st));
     // direction-encoding columns of dir_info (per-ray sums)
@@ -489,7 +498,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     sg.save = save; sg.G = G; sg.dz = at<float>(ws, L.dz); sg.dspre = at<float>(ws, L.dspre); sg.rayf = at<float>(ws, L.rayf);
     sg.Mtot = Mtot; sg.MSrows = Mtot + DUMP_ROWS; sg.B = B; sg.Nc = Nc; sg.Nf = Nf;
     sg.dW_color = dw[W_COLOR]; sg.db_color = dw[B_COLOR]; sg.dw_sigma = dw[W_SIGMA]; sg.db_sigma = dw[B_SIGMA]; sg.dW_dir = dw[W_DIR];
-    sg.sbuf = at<float>(ws, L.sbuf); sg.gdbuf = at<float>(ws, L.gdbuf);
+    sg.sbuf = at<float>(ws, L.sbuf); sg.gdbuf = at<float>(ws, L.gdbuf); sg.sums_done = ray_duty ? 1 : 0;
     HIP_TRY(launch_small_grads(sg, st));
   }
   return NERF_HIP_OK;

@@ -150,19 +150,28 @@ struct DwFrag {
 };
 
 // what a wave does besides its block (one extra duty per wave at most, so that the four waves of a workgroup stay level):
-constexpr int DW_PLAIN = 0, DW_BIAS = 1, DW_SIG = 2, DW_BIAS_LO = 3, DW_BIAS_HI = 4;
+constexpr int DW_PLAIN = 0, DW_BIAS = 1, DW_SIG = 2, DW_BIAS_LO = 3, DW_BIAS_HI = 4, DW_RAY_LO = 5, DW_RAY_HI = 6;
 // DW_BIAS  column sums of its 128 columns of G = bias gradient (4 adds per k-step)
 // DW_BIAS_LO / _HI  the same sums shared by the two waves that read the same G block: columns 4q, 4q+1 / 4q+2, 4q+3 (2 adds per k-step)
+// DW_RAY_LO / _HI   as DW_BIAS_LO / _HI, and the sums of every ray's rows are written out on the way (dir_info: the gamma_d columns need them)
+struct RayDuty {
+  float* out;        // [2][rays][128]
+  int nc, nf, rows_c;
+  int rays;
+};
 // DW_SIG   sigma head: wsig[col] += dsigma_pre[row] * X[row][col] for its 32 NCB columns of X (one more 4-byte load and 4 FMAs per k-step)
 
 // rows [r_begin, r_end) (wave-uniform, a multiple of 2 DW4_DEPTH rows long).  gbase / xbase / sbase: wave-uniform operand
 // pointers at row 0; goff / xoff / soff: this lane's byte offset inside a row pair (row h, column group q).
 template <int NCB, int DUTY>
 __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const float* __restrict__ xbase, const float* __restrict__ sbase, const unsigned goff,
-                                          const unsigned xoff, const unsigned soff, const int r_begin, const int r_end, f32x16 (&acc)[4][NCB], float (&bsum)[4]) {
+                                          const unsigned xoff, const unsigned soff, const int r_begin, const int r_end, f32x16 (&acc)[4][NCB], float (&bsum)[4],
+                                          const RayDuty rd = RayDuty{nullptr, 0, 0, 0, 0}, const int lane = 0) {
   typedef typename DwVecB<NCB>::type VB;
   constexpr int D = DW4_DEPTH;
+  constexpr bool RAY = DUTY == DW_RAY_LO || DUTY == DW_RAY_HI;
   DwFrag<NCB> s[D];
+  float rs[2] = {0.f, 0.f};  // RAY: this lane's sums over the rows of the current ray (its two columns, its row parity)
   const int r_last = r_end - 2;
   auto load = [&](int r, DwFrag<NCB>& S) {
     r = r <= r_last ? r : r_last;  // the prefetches past the end re-read the last row pair (valid memory, never multiplied)
@@ -199,7 +208,19 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[2]) : "v"(S.a.z));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[3]) : "v"(S.a.w));
     }
+    if (DUTY == DW_RAY_LO) {
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(rs[0]) : "v"(S.a.x));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(rs[1]) : "v"(S.a.y));
+    }
+    if (DUTY == DW_RAY_HI) {
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(rs[0]) : "v"(S.a.z));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(rs[1]) : "v"(S.a.w));
+    }
   };
+  // RAY: which ray the range starts in and how many of its rows are left (ranges start and end on ray boundaries: dw_ray_duty_ok)
+  bool fine = RAY && r_begin >= rd.rows_c;
+  int ray = !RAY ? 0 : (fine ? (r_begin - rd.rows_c) / rd.nf : r_begin / rd.nc);
+  int left = fine ? rd.nf : rd.nc;
   static_for<D - 1>([&](auto I) {  // in ring order (left alone the scheduler issues them last to first, and the loop's first wait drains the ring)
     load(r_begin + 2 * (int)I, s[I]);
     __builtin_amdgcn_sched_barrier(0);
@@ -212,6 +233,24 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
       mul(s[i]);
       __builtin_amdgcn_sched_barrier(0);
     });
+    if (RAY) {  // (wave-uniform) a ray's rows end with this round: its sums go out, the column sums take them over
+      left -= 2 * D;
+      if (left == 0) {
+        constexpr int c0 = DUTY == DW_RAY_LO ? 0 : 2;
+        bsum[c0] += rs[0];
+        bsum[c0 + 1] += rs[1];
+        const float t0 = rs[0] + __shfl_xor(rs[0], 32), t1 = rs[1] + __shfl_xor(rs[1], 32);
+        if (lane < 32) *reinterpret_cast<float2*>(rd.out + ((size_t)(fine ? rd.rays : 0) + ray) * 128 + 4 * lane + c0) = make_float2(t0, t1);
+        rs[0] = 0.f;
+        rs[1] = 0.f;
+        ++ray;
+        if (!fine && r0 + 2 * D == rd.rows_c) {  // the coarse pass's rows end here; the fine pass's follow
+          fine = true;
+          ray = 0;
+        }
+        left = fine ? rd.nf : rd.nc;
+      }
+    }
   }
 }
 
@@ -234,8 +273,8 @@ __device__ __forceinline__ void dw_stream_tail(const float* __restrict__ gbase, 
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(b, cb), acc[ca][cb], 0, 0, 0);
     if (duty == DW_BIAS) { bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w; }
-    if (duty == DW_BIAS_LO) { bsum[0] += a.x; bsum[1] += a.y; }
-    if (duty == DW_BIAS_HI) { bsum[2] += a.z; bsum[3] += a.w; }
+    if (duty == DW_BIAS_LO || duty == DW_RAY_LO) { bsum[0] += a.x; bsum[1] += a.y; }  // (the ray duties never get here: dw_ray_duty_ok)
+    if (duty == DW_BIAS_HI || duty == DW_RAY_HI) { bsum[2] += a.z; bsum[3] += a.w; }
     if (duty == DW_SIG) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) bsum[cb] = __builtin_fmaf(sg, comp(b, cb), bsum[cb]);
@@ -272,10 +311,11 @@ __host__ __device__ inline int dwi_duty(const DwItem& p, int bi, int bj) {
     return p.db ? 1 : 0;                             // DW_BIAS
   }
   if (!p.db) return 0;
+  if (in_blocks == 2 && p.raysum) return bj == 0 ? 5 : 6;  // DW_RAY_LO / DW_RAY_HI: the same halves, per-ray sums written on the way
   if (in_blocks == 2) return bj == 0 ? 3 : 4;        // DW_BIAS_LO / DW_BIAS_HI: half the sums on each of the two waves of a G block
   return bj == 0 ? 1 : 0;                            // DW_BIAS (one wave per G block)
 }
-__host__ __device__ inline bool dwi_sums_columns(int duty) { return duty == 1 || duty == 3 || duty == 4; }
+__host__ __device__ inline bool dwi_sums_columns(int duty) { return duty == 1 || duty >= 3; }
 
 // The colour head as one thin product: A = the [rows][4] buffer (dz_r, dz_g, dz_b, dsigma_pre), one 32-row output tile per wave,
 // X = c in two 64-column blocks x four row sub-ranges; rows 0..2 of the result are dW_color, the column sums of A (waves of
@@ -375,6 +415,15 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
       } else if (NCB == 4 && duty == DW_BIAS_HI) {
         asm volatile("; column sums, high half" ::: "memory");
         dw_stream<NCB, NCB == 4 ? DW_BIAS_HI : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
+      } else if (NCB == 4 && (duty == DW_RAY_LO || duty == DW_RAY_HI)) {
+        const RayDuty rd{p.raysum, p.ray_nc, p.ray_nf, p.rows_c, p.rows_c / (p.ray_nc > 0 ? p.ray_nc : 1)};
+        if (duty == DW_RAY_LO) {
+          asm volatile("; per-ray sums, low half" ::: "memory");
+          dw_stream<NCB, NCB == 4 ? DW_RAY_LO : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum, rd, lane);
+        } else {
+          asm volatile("; per-ray sums, high half" ::: "memory");
+          dw_stream<NCB, NCB == 4 ? DW_RAY_HI : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum, rd, lane);
+        }
       } else if (NCB == 4 && duty == DW_SIG) {
         asm volatile("; sigma head" ::: "memory");
         dw_stream<NCB, NCB == 4 ? DW_SIG : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
@@ -525,6 +574,17 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
   } else {
     p.dW2[col - n_b] = s;
   }
+}
+
+// The dir_info product may carry the per-ray sums when every wave's row range starts and ends on ray boundaries of its pass and no
+// range is ragged (then the pipelined loop runs everywhere): ranges are multiples of both sample counts, the coarse pass's rows
+// are a multiple of the fine pass's samples per ray, and the rows fill whole ranges.
+bool dw_ray_duty_ok(const DwItem& p, long long Mtot, int B, int Nc, int Nf) {
+  if (p.thin || dwi_ncb(p) != 4 || dwi_in_blocks(p) != 2 || !p.db || p.has_sig) return false;
+  if (Nc % (2 * DW4_DEPTH) || Nf % (2 * DW4_DEPTH) || Mtot != (long long)B * (Nc + Nf)) return false;
+  const int msubs = dwi_msubs(p), gran = 2 * DW4_DEPTH * msubs, Mrows = (int)Mtot;
+  const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran, per_wave = per_wg / msubs;
+  return per_wave % Nc == 0 && per_wave % Nf == 0 && ((long long)B * Nc) % Nf == 0 && Mrows % per_wave == 0;
 }
 
 size_t dw_item_slab_floats(const DwItem& p) { return (size_t)p.nwg * dwi_wg_floats(p); }

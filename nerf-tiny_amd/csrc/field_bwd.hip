@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
 // direction-encoding columns of dir_info (the weight-gradient GEMMs and the thin heads live in dw_f32.hip)
 // ------------------------------------------------------------------------------------------------
 // direction-encoding columns of dir_info: dW_d[o][k<24] = sum_ray gamma_d[ray][k] * sum_{samples of ray} dpre_d[m][o]
+// (fallback: ray counts / sample counts for which the dir_info product cannot carry the sums, dw_ray_duty_ok)
 __global__ __launch_bounds__(512) void k_dir_ray_sums(const SmallGradArgs a) {
   // one ray per block: thread (part, column); the four parts take every fourth row, four partial sums each (fixed order)
   __shared__ float part_sum[4][HALF];
@@ -257,18 +258,25 @@ __global__ __launch_bounds__(512) void k_dir_ray_sums(const SmallGradArgs a) {
   span(f0, a.Nf);
   part_sum[part][t] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (part == 0) a.sbuf[(size_t)ray * HALF + t] = (part_sum[0][t] + part_sum[1][t]) + (part_sum[2][t] + part_sum[3][t]);
-  if (threadIdx.x < 12) {
-    const int c = threadIdx.x >> 2, l = threadIdx.x & 3;
+  if (part == 0) {
+    a.sbuf[(size_t)ray * HALF + t] = (part_sum[0][t] + part_sum[1][t]) + (part_sum[2][t] + part_sum[3][t]);
+    a.sbuf[((size_t)a.B + ray) * HALF + t] = 0.f;  // (the sum over both passes sits in the coarse half)
+  }
+}
+constexpr int DG_CHUNKS = 64;
+// gamma_d of every ray (nerf.py:292-296 on the normalised direction) and the zeroed destination columns
+__global__ __launch_bounds__(128) void k_dir_prep(const SmallGradArgs a) {
+  const int i = blockIdx.x * 128 + threadIdx.x;  // (ray, pair)
+  if (blockIdx.x == 0) {
+    const int o = threadIdx.x;
+    for (int k = 0; k < DIR_DIM; ++k) a.dW_dir[(size_t)o * (WIDTH + DIR_DIM) + k] = 0.f;
+  }
+  if (i < a.B * 12) {
+    const int ray = i / 12, t = i - ray * 12, c = t >> 2, l = t & 3;
     const float ph = a.rayf[(size_t)ray * RAYF + RF_DWRD + c] * __uint_as_float(kFreqDirBits[l]);
     a.gdbuf[(size_t)ray * DIR_DIM + c * 8 + 2 * l] = sinf(ph);
     a.gdbuf[(size_t)ray * DIR_DIM + c * 8 + 2 * l + 1] = cosf(ph);
   }
-}
-constexpr int DG_CHUNKS = 64;
-__global__ __launch_bounds__(128) void k_dir_gamma_zero(const SmallGradArgs a) {
-  const int o = threadIdx.x;
-  for (int k = 0; k < DIR_DIM; ++k) a.dW_dir[(size_t)o * (WIDTH + DIR_DIM) + k] = 0.f;
 }
 __global__ __launch_bounds__(128) void k_dir_gamma_dw(const SmallGradArgs a) {
   // block (k, chunk of rays), thread o (0..127); one float atomic per (block, o)
@@ -276,8 +284,9 @@ __global__ __launch_bounds__(128) void k_dir_gamma_dw(const SmallGradArgs a) {
   const int per = (a.B + DG_CHUNKS - 1) / DG_CHUNKS;
   const int r0 = blockIdx.y * per;
   const int r1 = (r0 + per) < a.B ? (r0 + per) : a.B;
+  const float* sf = a.sbuf + (size_t)a.B * HALF;  // sums over the fine pass's rows
   float s = 0.f;
-  for (int ray = r0; ray < r1; ++ray) s = __builtin_fmaf(a.sbuf[(size_t)ray * HALF + o], a.gdbuf[(size_t)ray * DIR_DIM + k], s);
+  for (int ray = r0; ray < r1; ++ray) s = __builtin_fmaf(a.sbuf[(size_t)ray * HALF + o] + sf[(size_t)ray * HALF + o], a.gdbuf[(size_t)ray * DIR_DIM + k], s);
   if (r0 < r1) atomicAdd(a.dW_dir + (size_t)o * (WIDTH + DIR_DIM) + k, s);
 }
 
@@ -297,8 +306,8 @@ hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st) {
 }
 
 hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_dir_ray_sums, dim3(a.B), dim3(512), 0, st, a);
-  hipLaunchKernelGGL(k_dir_gamma_zero, dim3(1), dim3(128), 0, st, a);
+  if (!a.sums_done) hipLaunchKernelGGL(k_dir_ray_sums, dim3(a.B), dim3(512), 0, st, a);
+  hipLaunchKernelGGL(k_dir_prep, dim3((a.B * 12 + 127) / 128), dim3(128), 0, st, a);
   hipLaunchKernelGGL(k_dir_gamma_dw, dim3(DIR_DIM, DG_CHUNKS), dim3(128), 0, st, a);
   return hipGetLastError();
 }

@@ -161,6 +161,10 @@ struct DwItem {
   float* db2;              // thin only: db_sigma[1]
   int thin;                // 1: the colour head (and both heads' bias gradients) as one thin product
   int has_sig;             // 1: the sigma head rides on this product (X = h7): dW2 from the waves that hold X's columns
+  float* raysum;           // dir_info product, rows aligned to rays (dw_ray_duty_ok): the column-sum waves also write the per-ray sums of G,
+                           // [2][rays][128] (coarse rows, fine rows) -- the scratch of the gamma_d columns' kernels; else null
+  int ray_nc, ray_nf;      // samples per ray of the coarse / fine pass
+  int rows_c;              // rows of the coarse pass (= rays * ray_nc), the fine pass's rows follow
   int wg0, nwg;            // workgroups [wg0, wg0 + nwg) of the launch work on this product, each on 1/nwg of the rows
   long long slab_off;      // floats: this product's slabs inside DwBatch::slabs
   unsigned long long* stamps;  // diagnostic build only: per-wave (start, end, xcc, hw id) records
@@ -205,7 +209,8 @@ struct SmallGradArgs {
   long long MSrows;        // rows per tensor of save / G (Mtot + DUMP_ROWS)
   int B, Nc, Nf;
   float *dW_color, *db_color, *dw_sigma, *db_sigma, *dW_dir;  // destinations (dW_dir: [128][280], cols 0..23 written)
-  float* sbuf;             // [B][128] scratch: per-ray sums of dpre_dir
+  float* sbuf;             // [2][B][128] scratch: per-ray sums of dpre_dir over the coarse / the fine rows
+  int sums_done;           // 1: sbuf was written by the dir_info product (DwItem::raysum); 0: k_dir_ray_sums does it
   float* gdbuf;            // [B][24]  scratch: gamma_dir per ray
 };
 
@@ -223,6 +228,7 @@ hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni
 hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st);  // every product -> its slabs, ONE launch
 hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st);                         // all slabs of the step -> gradients
 size_t dw_item_slab_floats(const DwItem& p);
+bool dw_ray_duty_ok(const DwItem& p, long long Mtot, int B, int Nc, int Nf);  // may the product of G_dir carry the per-ray sums?
 hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st);
 size_t merge_bwd_lds_bytes(int N);
 hipError_t launch_merge_bwd(const MergeBwdArgs& a, hipStream_t st);

@@ -68,7 +68,7 @@ def main():
             chk.append(("dir_info.0.bias", g["dir_info.0.bias"], Gt(9).sum(0)[:128]))
             gd9 = G[9]
             raysum = gd9[:B * Nc].view(B, Nc, 256)[:, :, :128].sum(1) + gd9[B * Nc:Mtot].view(B, Nf, 256)[:, :, :128].sum(1)
-            chk.append(("per-ray sums of dpre_dir (sbuf)", view("sbuf", (B, 128)), raysum))
+            chk.append(("per-ray sums of dpre_dir (sbuf)", view("sbuf", (2, B, 128)).sum(0), raysum))
             chk.append(("dir_info.0.weight[:,:24]", g["dir_info.0.weight"][:, :24], raysum.T @ view("gdbuf", (B, 24))))
             chk.append(("color_layer.0.weight", g["color_layer.0.weight"], dz[:, :3].T @ X(9)[:, :128]))
             chk.append(("color_layer.0.bias", g["color_layer.0.bias"], dz[:, :3].sum(0)))
