@@ -310,8 +310,8 @@ def rooflines(leg, prof, b_local, steps):
 
 # launches of the fp32 weight-gradient phase per train step (dw_f32.hip, field_bwd.hip): the 128 x 128-block products (layers 1-7,
 # point_info + sigma head, dir_info), the 128 x 64-block ones (layer 0, layer 4's skip columns), the colour head, the reduce, and the
-# two small kernels of dir_info's direction-encoding columns (their per-ray sums come out of the dir_info product)
-DW_LAUNCHES = {"k_dw4<4>": 9, "k_dw4<2>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_dir_prep": 1, "k_dir_gamma_dw": 1}
+# three small kernels of dir_info's direction-encoding columns (their per-ray sums come out of the dir_info product)
+DW_LAUNCHES = {"k_dw4<4>": 9, "k_dw4<2>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_dir_prep": 1, "k_dir_gamma_part": 1, "k_dir_gamma_final": 1}
 DW_BF16_KIB_PER_WAVE_BLOCK = 318  # G and X pieces of bf16_common.h over the 11 products
 
 

@@ -499,7 +499,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     sg.Mtot = Mtot; sg.MSrows = Mtot + DUMP_ROWS; sg.B = B; sg.Nc = Nc; sg.Nf = Nf;
     sg.dW_color = dw[W_COLOR]; sg.db_color = dw[B_COLOR]; sg.dw_sigma = dw[W_SIGMA]; sg.db_sigma = dw[B_SIGMA]; sg.dW_dir = dw[W_DIR];
     sg.sbuf = at<float>(ws, L.sbuf); sg.gdbuf = at<float>(ws, L.gdbuf); sg.sums_done = ray_duty ? 1 : 0;
-    HIP_TRY(launch_small_grads(sg, st));
+    HIP_TRY(launch_small_grads(sg, slabs, st));  // (the slabs are free after the reduce: scratch of the gamma_d columns' two-step sum)
   }
   return NERF_HIP_OK;
 }

@@ -7,7 +7,8 @@
 //                     FINE also back-propagates into the encoding inputs: d loss/d gamma_p (skip layer +
 //                     layer 0) -> d loss/d point -> d loss/d t_fine  (the reference does NOT detach t_fine,
 //                     nerf.py:259 -- quirk Q9).
-//  k_dir_*            the direction-encoding columns of dir_info (per-ray sums of dpre_dir times gamma_d).
+//  k_dir_*            the direction-encoding columns of dir_info: sum over rays of gamma_d (x) (per-ray sums of dpre_dir), summed
+//                     in a fixed order (no float atomics); the per-ray sums normally come out of the dir_info product (dw_f32.hip).
 //  (the weight-gradient GEMMs incl. the colour / sigma heads: dw_f32.hip)
 //
 // Autograd spans replaced: backward of Network.forward (nerf.py:101-124), Encoder.forward (nerf.py:135-167)
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
 // direction-encoding columns of dir_info (the weight-gradient GEMMs and the thin heads live in dw_f32.hip)
 // ------------------------------------------------------------------------------------------------
 // direction-encoding columns of dir_info: dW_d[o][k<24] = sum_ray gamma_d[ray][k] * sum_{samples of ray} dpre_d[m][o]
-// (fallback: ray counts / sample counts for which the dir_info product cannot carry the sums, dw_ray_duty_ok)
+// per-ray sums (fallback: ray counts / sample counts for which the dir_info product cannot carry the sums, dw_ray_duty_ok)
 __global__ __launch_bounds__(512) void k_dir_ray_sums(const SmallGradArgs a) {
   // one ray per block: thread (part, column); the four parts take every fourth row, four partial sums each (fixed order)
   __shared__ float part_sum[4][HALF];
@@ -263,14 +264,10 @@ __global__ __launch_bounds__(512) void k_dir_ray_sums(const SmallGradArgs a) {
     a.sbuf[((size_t)a.B + ray) * HALF + t] = 0.f;  // (the sum over both passes sits in the coarse half)
   }
 }
-constexpr int DG_CHUNKS = 64;
-// gamma_d of every ray (nerf.py:292-296 on the normalised direction) and the zeroed destination columns
+constexpr int DG_CHUNKS = 128;
+// gamma_d of every ray (nerf.py:292-296 on the normalised direction)
 __global__ __launch_bounds__(128) void k_dir_prep(const SmallGradArgs a) {
   const int i = blockIdx.x * 128 + threadIdx.x;  // (ray, pair)
-  if (blockIdx.x == 0) {
-    const int o = threadIdx.x;
-    for (int k = 0; k < DIR_DIM; ++k) a.dW_dir[(size_t)o * (WIDTH + DIR_DIM) + k] = 0.f;
-  }
   if (i < a.B * 12) {
     const int ray = i / 12, t = i - ray * 12, c = t >> 2, l = t & 3;
     const float ph = a.rayf[(size_t)ray * RAYF + RF_DWRD + c] * __uint_as_float(kFreqDirBits[l]);
@@ -278,16 +275,47 @@ __global__ __launch_bounds__(128) void k_dir_prep(const SmallGradArgs a) {
     a.gdbuf[(size_t)ray * DIR_DIM + c * 8 + 2 * l + 1] = cosf(ph);
   }
 }
-__global__ __launch_bounds__(128) void k_dir_gamma_dw(const SmallGradArgs a) {
-  // block (k, chunk of rays), thread o (0..127); one float atomic per (block, o)
-  const int k = blockIdx.x, o = threadIdx.x;
+// dW_dir[o][k < 24] = sum_ray gamma_d[ray][k] * (sum over the ray's samples of dpre_dir[.][o]) in two deterministic steps (no float
+// atomics): block = a chunk of rays, thread o keeps the 24 partial sums of its output row; then one thread per (o, k) adds the
+// chunks' partials in a fixed order.  `part` = [DG_CHUNKS][128][24] floats of scratch (the slab buffer, free by now).
+__global__ __launch_bounds__(128) void k_dir_gamma_part(const SmallGradArgs a, float* __restrict__ part) {
+  const int o = threadIdx.x;
   const int per = (a.B + DG_CHUNKS - 1) / DG_CHUNKS;
-  const int r0 = blockIdx.y * per;
+  const int r0 = blockIdx.x * per;
   const int r1 = (r0 + per) < a.B ? (r0 + per) : a.B;
   const float* sf = a.sbuf + (size_t)a.B * HALF;  // sums over the fine pass's rows
-  float s = 0.f;
-  for (int ray = r0; ray < r1; ++ray) s = __builtin_fmaf(a.sbuf[(size_t)ray * HALF + o] + sf[(size_t)ray * HALF + o], a.gdbuf[(size_t)ray * DIR_DIM + k], s);
-  if (r0 < r1) atomicAdd(a.dW_dir + (size_t)o * (WIDTH + DIR_DIM) + k, s);
+  float acc[DIR_DIM];
+#pragma unroll
+  for (int k = 0; k < DIR_DIM; ++k) acc[k] = 0.f;
+  for (int ray = r0; ray < r1; ++ray) {
+    const float s = a.sbuf[(size_t)ray * HALF + o] + sf[(size_t)ray * HALF + o];
+    const float4* gd = reinterpret_cast<const float4*>(a.gdbuf + (size_t)ray * DIR_DIM);  // the same 96 bytes for every thread
+#pragma unroll
+    for (int k4 = 0; k4 < DIR_DIM / 4; ++k4) {
+      const float4 g = gd[k4];
+      acc[4 * k4 + 0] = __builtin_fmaf(s, g.x, acc[4 * k4 + 0]);
+      acc[4 * k4 + 1] = __builtin_fmaf(s, g.y, acc[4 * k4 + 1]);
+      acc[4 * k4 + 2] = __builtin_fmaf(s, g.z, acc[4 * k4 + 2]);
+      acc[4 * k4 + 3] = __builtin_fmaf(s, g.w, acc[4 * k4 + 3]);
+    }
+  }
+  float4* out = reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * HALF + o) * DIR_DIM);
+#pragma unroll
+  for (int k4 = 0; k4 < DIR_DIM / 4; ++k4) out[k4] = make_float4(acc[4 * k4], acc[4 * k4 + 1], acc[4 * k4 + 2], acc[4 * k4 + 3]);
+}
+__global__ __launch_bounds__(256) void k_dir_gamma_final(const SmallGradArgs a, const float* __restrict__ part) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // (o, k)
+  if (e >= HALF * DIR_DIM) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+  for (int c = 0; c < DG_CHUNKS; c += 4) {
+    s0 += part[(size_t)c * HALF * DIR_DIM + e];
+    s1 += part[(size_t)(c + 1) * HALF * DIR_DIM + e];
+    s2 += part[(size_t)(c + 2) * HALF * DIR_DIM + e];
+    s3 += part[(size_t)(c + 3) * HALF * DIR_DIM + e];
+  }
+  const int o = e / DIR_DIM, k = e - o * DIR_DIM;
+  a.dW_dir[(size_t)o * (WIDTH + DIR_DIM) + k] = (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -305,10 +333,11 @@ hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st) {
+hipError_t launch_small_grads(const SmallGradArgs& a, float* scratch, hipStream_t st) {
   if (!a.sums_done) hipLaunchKernelGGL(k_dir_ray_sums, dim3(a.B), dim3(512), 0, st, a);
   hipLaunchKernelGGL(k_dir_prep, dim3((a.B * 12 + 127) / 128), dim3(128), 0, st, a);
-  hipLaunchKernelGGL(k_dir_gamma_dw, dim3(DIR_DIM, DG_CHUNKS), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(k_dir_gamma_part, dim3(DG_CHUNKS), dim3(128), 0, st, a, scratch);
+  hipLaunchKernelGGL(k_dir_gamma_final, dim3((HALF * DIR_DIM + 255) / 256), dim3(256), 0, st, a, scratch);
   return hipGetLastError();
 }
 

@@ -229,7 +229,7 @@ hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t
 hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st);                         // all slabs of the step -> gradients
 size_t dw_item_slab_floats(const DwItem& p);
 bool dw_ray_duty_ok(const DwItem& p, long long Mtot, int B, int Nc, int Nf);  // may the product of G_dir carry the per-ray sums?
-hipError_t launch_small_grads(const SmallGradArgs& a, hipStream_t st);
+hipError_t launch_small_grads(const SmallGradArgs& a, float* scratch, hipStream_t st);  // scratch: >= 128 * 128 * 24 floats (the slab buffer, after the reduce)
 size_t merge_bwd_lds_bytes(int N);
 hipError_t launch_merge_bwd(const MergeBwdArgs& a, hipStream_t st);
 hipError_t launch_coarse_bwd(const CoarseBwdArgs& a, hipStream_t st);
