@@ -67,10 +67,10 @@ long long build_dw_batch(DwBatch& b, const float* G, const float* save, const fl
   auto Gt = [&](int t) { return G ? G + (size_t)t * MS : nullptr; };
   auto St = [&](int t) { return save ? save + (size_t)t * MS : nullptr; };
   auto D = [&](int i) { return dw ? dw[i] : nullptr; };
-  add(Gt(0), 256, St(S_GP), 64, POINT_DIM, D(0), POINT_DIM, 0, D(1), 0.25f);                          // layer 0: X = gamma_p
   for (int l = 1; l <= 7; ++l)                                                                          // layers 1..7 (layer 4: hidden columns)
     add(Gt(l), 256, St(l - 1), 256, 256, D(2 * l), l == 4 ? WIDTH + POINT_DIM : WIDTH, 0, D(2 * l + 1), 1.0f);
   add(Gt(4), 256, St(S_GP), 64, POINT_DIM, D(8), WIDTH + POINT_DIM, WIDTH, nullptr, 0.25f);            // layer 4, skip columns
+  add(Gt(0), 256, St(S_GP), 64, POINT_DIM, D(0), POINT_DIM, 0, D(1), 0.25f);                          // layer 0: X = gamma_p
   DwItem& pi = add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI), 1.0f);                  // point_info ...
   pi.has_sig = 1; pi.sig = dz4 ? dz4 + 3 : nullptr; pi.dW2 = D(W_SIGMA);                                // ... + the sigma head (same X = h7)
   add(Gt(G_D), 128, St(S_FEAT), 256, 256, D(W_DIR), WIDTH + DIR_DIM, DIR_DIM, D(B_DIR), 0.5f);         // dir_info, feature columns
@@ -479,7 +479,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     float* slabs = at<float>(ws, L.slabs);
     batch.slabs = slabs;
 #ifdef NERF_STAMPS
-    batch.item[1].stamps = at<unsigned long long>(ws, L.dbg) + 64;  // layer 1: a 256 x 256 product
+    batch.item[0].stamps = at<unsigned long long>(ws, L.dbg) + 64;  // layer 1: a 256 x 256 product
 #endif
     // the dir_info product writes the per-ray sums of its G operand on the way when its row ranges line up with the rays
     bool ray_duty = false;
