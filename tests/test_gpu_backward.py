@@ -131,9 +131,10 @@ def test_chain_and_weight_gradients_on_coarse_only_loss(oracle, pkg, dev, name):
     print(f"{name}: coarse-only loss, worst grad L2-rel {worst:.2e}")
 
 
-@pytest.mark.parametrize("rays", [333, 99, 7])
+@pytest.mark.parametrize("rays", [701, 333, 99, 7])
 def test_weight_gradients_on_ragged_row_counts(oracle, pkg, dev, rays):
-    """Row counts that do not fill the weight-gradient kernels' row ranges: 333 rays = 63,936 rows leave a ragged last range in every
+    """Row counts that do not fill the weight-gradient kernels' row ranges: 701 rays leave a ragged last range in all three kernels
+    (128 x 128 and 128 x 64 blocks and the thin colour-head product), 333 rays = 63,936 rows in every MFMA-bound
     product shape (the per-row tail loop with its clamped rows, incl. the column-sum and sigma-head duties), 99 rays in the
     256 x 256 ones only, 7 rays leave most of the 256 workgroups without rows.  Bar 3e-4 per tensor: layer 0's weight gradient
     (the ill-conditioned one, see _sensitivity_band) sits at 1.5e-4 for 333 rays in fp32 on either side, while ONE dropped or doubled row
