@@ -150,6 +150,22 @@ def test_weight_gradients_on_ragged_row_counts(oracle, pkg, dev, rays):
         assert e < 3e-4, (k, e)
 
 
+def test_train_step_is_bit_reproducible(oracle, pkg, dev):
+    """Every sum of the fp32 train step runs in a fixed order (slab reduce, column sums, the gamma_d columns' two-step sum; no float
+    atomics): the same weights and batch give the same 24 gradients bit for bit, launch after launch."""
+    g, inputs, Nc, Nf, w = _case(oracle, "cfg1_lego_crop32")
+    ref = None
+    for rep in range(4):
+        m, loss = _train_step(pkg, oracle, dev, w, inputs, Nc, Nf)
+        grads = [q.grad.detach().clone() for q in m.network.parameters()]
+        if ref is None:
+            ref, lref = grads, float(loss.detach())
+            continue
+        assert float(loss.detach()) == lref
+        for (k, _), a, b in zip(m.network.named_parameters(), grads, ref):
+            assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_merge_backward_given_reference_sort_order(oracle, pkg, dev, name):
     """rows a8/a9 backward: d sigma, d rgb of both passes and the merge part of d t_fine (workspace buffers after
