@@ -61,14 +61,23 @@ __device__ __forceinline__ PackDesc pack_desc(int s) {
   }
 }
 
-__global__ void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg) {
+// first float4 of every segment (seg_off4 evaluated at compile time: called per thread it is a loop inside a loop)
+struct SegOffTable { int v[NSEG + 1]; };
+constexpr SegOffTable make_seg_off_table() {
+  SegOffTable t{};
+  for (int s = 0; s <= NSEG; ++s) t.v[s] = seg_off4(s);
+  return t;
+}
+__constant__ const SegOffTable kSegOff = make_seg_off_table();
+
+__global__ __launch_bounds__(256) void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg) {
   // one thread per float4 of the packed image
-  const int total = seg_off4(nseg);
+  const int total = kSegOff.v[nseg];
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     int s = 0;
 #pragma unroll 1
-    while (s + 1 < nseg && idx >= seg_off4(s + 1)) ++s;
-    const int local = idx - seg_off4(s);
+    while (s + 1 < nseg && idx >= kSegOff.v[s + 1]) ++s;
+    const int local = idx - kSegOff.v[s];
     const int kbn = seg_kb(s);
     const int lane = local & 63;
     const int kb = (local >> 6) % kbn;
@@ -77,15 +86,22 @@ __global__ void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg) 
     const float* W = w.p[d.src];
     const int f = ft * 32 + (lane & 31);
     const int k0 = kb * 8 + 4 * (lane >> 5);
-    float v[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int k = k0 + c;
-      float x = 0.f;
-      if (f < d.rows && k < d.cols) x = d.transposed ? W[(size_t)k * d.ld + d.col0 + f] : W[(size_t)f * d.ld + d.col0 + k];
-      v[c] = x;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!d.transposed) {
+      // four consecutive inputs of one output row: one 16-byte load (every row length and column offset is a multiple of 4 floats,
+      // and so is every segment's input count, so a group is either all inside or all padding)
+      if (f < d.rows && k0 < d.cols) {
+        const float* src = W + (size_t)f * d.ld + d.col0 + k0;
+        if ((reinterpret_cast<uintptr_t>(W) & 15) == 0) v = *reinterpret_cast<const float4*>(src);
+        else v = make_float4(src[0], src[1], src[2], src[3]);  // a caller's parameter view that is only 4-byte aligned
+      }
+    } else if (f < d.rows) {
+      if (k0 + 0 < d.cols) v.x = W[(size_t)(k0 + 0) * d.ld + d.col0 + f];
+      if (k0 + 1 < d.cols) v.y = W[(size_t)(k0 + 1) * d.ld + d.col0 + f];
+      if (k0 + 2 < d.cols) v.z = W[(size_t)(k0 + 2) * d.ld + d.col0 + f];
+      if (k0 + 3 < d.cols) v.w = W[(size_t)(k0 + 3) * d.ld + d.col0 + f];
     }
-    out[idx] = make_float4(v[0], v[1], v[2], v[3]);
+    out[idx] = v;
   }
 }
 
