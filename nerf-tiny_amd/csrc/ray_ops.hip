@@ -211,6 +211,37 @@ __global__ __launch_bounds__(256) void k_coarse(const CoarseArgs a) {
 // Ties are broken by original index (a stable sort); indices are kept for the backward pass.
 // ---------------------------------------------------------------------------------------------
 
+// bitonic sort of five independent 256-element channels in LDS by one wave (values only; equal keys are interchangeable)
+template <int K, int J>
+__device__ __forceinline__ void sort256_stage(float* val, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int tI = lane + 64 * it;
+    const int i = ((tI & ~(J - 1)) << 1) | (tI & (J - 1));  // element with bit J clear; its partner is i + J
+    const bool asc = (i & K) == 0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      float* q = val + c * 256 + i;
+      const float x = q[0], y = q[J];
+      const bool sw = (x > y) == asc;  // one compare, one scalar xnor with the stage's direction mask, two selects
+      q[0] = sw ? y : x;
+      q[J] = sw ? x : y;
+    }
+  }
+  __syncthreads();
+}
+template <int K, int J>
+__device__ __forceinline__ void sort256_merge(float* val, int lane) {
+  sort256_stage<K, J>(val, lane);
+  if constexpr (J > 1) sort256_merge<K, J / 2>(val, lane);
+}
+template <int K>
+__device__ __forceinline__ void sort256_from(float* val, int lane) {
+  sort256_merge<K, K / 2>(val, lane);
+  if constexpr (K < 256) sort256_from<K * 2>(val, lane);
+}
+__device__ __forceinline__ void sort256_values(float* val, int lane) { sort256_from<2>(val, lane); }
+
 template <bool WITH_IDX>  // WITH_IDX: carry the original index (stable order + permutation for backward)
 __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -238,6 +269,11 @@ __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
     }
   }
   __syncthreads();
+  if (!WITH_IDX && P == 256) {
+    // values only, the usual size (64 + 128 samples): the network fully unrolled, so that a pair is ONE ds_read2_b32 / ds_write2_b32
+    // with the partner's distance as an immediate, written back as (min, max) without a branch -- half the LDS instructions
+    sort256_values(val, lane);
+  } else
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int tI = lane; tI < (P >> 1); tI += 64) {
