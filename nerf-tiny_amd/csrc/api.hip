@@ -52,14 +52,12 @@ int check_sizes(int B, int Nc, int Nf) {
 size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 
 
-// The twelve weight-gradient products (eleven MFMA-bound ones, one of them carrying the sigma head, + the thin colour head) of the fp32 train step (dw_f32.hip) with their slab offsets; pointers are filled in
-// by nerf_hip_backward (null here: only sizes matter for the layout).
+// The twelve weight-gradient products of the fp32 train step (dw_f32.hip) -- eleven MFMA-bound ones, one of them carrying the sigma
+// head, + the thin colour head -- in launch order, with their slab offsets; pointers are filled in by nerf_hip_backward (null
+// here: only sizes matter for the layout).
 long long build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw) {
   memset(&b, 0, sizeof(b));
-  // MFMA time of each product in units of a 256 x 256 one (the thin colour-head product is load-bound)
-  float units[DW_MAX_ITEMS];
-  auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db, float u) -> DwItem& {
-    units[b.n] = u;
+  auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db) -> DwItem& {
     DwItem& it = b.item[b.n++];
     it.G = g; it.X = x; it.nout = nout; it.nin = nin; it.nin_real = nin_real; it.dW = dW; it.ldw = ldw; it.col0 = col0; it.db = db;
     return it;
@@ -67,23 +65,21 @@ long long build_dw_batch(DwBatch& b, const float* G, const float* save, const fl
   auto Gt = [&](int t) { return G ? G + (size_t)t * MS : nullptr; };
   auto St = [&](int t) { return save ? save + (size_t)t * MS : nullptr; };
   auto D = [&](int i) { return dw ? dw[i] : nullptr; };
-  for (int l = 1; l <= 7; ++l)                                                                          // layers 1..7 (layer 4: hidden columns)
-    add(Gt(l), 256, St(l - 1), 256, 256, D(2 * l), l == 4 ? WIDTH + POINT_DIM : WIDTH, 0, D(2 * l + 1), 1.0f);
-  add(Gt(4), 256, St(S_GP), 64, POINT_DIM, D(8), WIDTH + POINT_DIM, WIDTH, nullptr, 0.25f);            // layer 4, skip columns
-  add(Gt(0), 256, St(S_GP), 64, POINT_DIM, D(0), POINT_DIM, 0, D(1), 0.25f);                          // layer 0: X = gamma_p
-  DwItem& pi = add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI), 1.0f);                  // point_info ...
-  pi.has_sig = 1; pi.sig = dz4 ? dz4 + 3 : nullptr; pi.dW2 = D(W_SIGMA);                                // ... + the sigma head (same X = h7)
-  add(Gt(G_D), 128, St(S_FEAT), 256, 256, D(W_DIR), WIDTH + DIR_DIM, DIR_DIM, D(B_DIR), 0.5f);         // dir_info, feature columns
-  DwItem& th = add(dz4, 32, St(S_C), 128, 128, D(W_COLOR), HALF, 0, D(B_COLOR), 0.1f);                 // colour head (X = c) + the bias gradients of both heads
+  for (int l = 1; l <= 7; ++l)                                                                   // layers 1..7 (layer 4: hidden columns)
+    add(Gt(l), 256, St(l - 1), 256, 256, D(2 * l), l == 4 ? WIDTH + POINT_DIM : WIDTH, 0, D(2 * l + 1));
+  add(Gt(4), 256, St(S_GP), 64, POINT_DIM, D(8), WIDTH + POINT_DIM, WIDTH, nullptr);            // layer 4, skip columns
+  // layer 0 (X = gamma_p): HBM-bound like the one above; NOT first -- right behind the chain kernel it ran 20 % longer
+  add(Gt(0), 256, St(S_GP), 64, POINT_DIM, D(0), POINT_DIM, 0, D(1));
+  DwItem& pi = add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI));                  // point_info ...
+  pi.has_sig = 1; pi.sig = dz4 ? dz4 + 3 : nullptr; pi.dW2 = D(W_SIGMA);                         // ... + the sigma head (same X = h7)
+  add(Gt(G_D), 128, St(S_FEAT), 256, 256, D(W_DIR), WIDTH + DIR_DIM, DIR_DIM, D(B_DIR));         // dir_info, feature columns
+  DwItem& th = add(dz4, 32, St(S_C), 128, 128, D(W_COLOR), HALF, 0, D(B_COLOR));                 // colour head (X = c) + the bias gradients of both heads
   th.thin = 1; th.db2 = D(B_SIGMA);
   // Every product gets ALL DW_WGS workgroups in a launch of its own.  (One launch for all products, the CUs dealt out in
-  // proportion to `units`, was built and measured: no gain (8.2 vs 8.1 ms for the phase).  See DESIGN.md section 4b.)
-  (void)units;
-  for (int i = 0; i < b.n; ++i) b.item[i].nwg = DW_WGS;
+  // proportion to their MFMA time, was built and measured in round 2: no gain.  See DESIGN.md section 4b.)
   long long off = 0;
-  int wg0 = 0;
-  (void)wg0;
   for (int i = 0; i < b.n; ++i) {
+    b.item[i].nwg = DW_WGS;
     b.item[i].wg0 = 0;
     b.item[i].slab_off = off; off += (long long)dw_item_slab_floats(b.item[i]);
   }
