@@ -211,36 +211,107 @@ __global__ __launch_bounds__(256) void k_coarse(const CoarseArgs a) {
 // Ties are broken by original index (a stable sort); indices are kept for the backward pass.
 // ---------------------------------------------------------------------------------------------
 
-// bitonic sort of five independent 256-element channels in LDS by one wave (values only; equal keys are interchangeable)
-template <int K, int J>
-__device__ __forceinline__ void sort256_stage(float* val, int lane) {
+// Bitonic sort of five independent 256-slot channels by one wave IN REGISTERS: lane l holds slots 4l .. 4l+3 of every channel, so
+// the 15 stages with partner distance 1 or 2 are lane-local and the 21 others exchange with lane l ^ (distance / 4) through DPP
+// (distance 4, 8), ds_swizzle (16 .. 64) or one permute (128) -- no LDS traffic between stages and no barriers (the LDS version
+// spent 36 barriers and ~500 two-address LDS instructions per ray).  Keys are the floats' order-preserving unsigned images
+// (sign flipped for positives, all bits for negatives: -0 sorts just below +0, otherwise the order of torch.sort); WITH_IDX carries
+// the original slot as the low half of a 64-bit key, which makes the order total (= a stable sort, as before).
+template <int D>
+__device__ __forceinline__ unsigned lane_xor_get(unsigned v) {  // v of lane (l ^ D)
+  if constexpr (D == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  else if constexpr (D < 32) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (D << 10));   // bit-mask mode: xor D inside 32 lanes
+  else return (unsigned)__shfl_xor((int)v, 32);
+}
+__device__ __forceinline__ unsigned sort_key(float x) {
+  const unsigned b = __float_as_uint(x);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float sort_unkey(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+
+template <bool WITH_IDX, int K, int J>
+__device__ __forceinline__ void sortreg_stage(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
+  if constexpr (J >= 4) {
+    constexpr int D = J / 4;
+    const bool upper = (lane & D) != 0;
+    const bool asc = K >= 256 ? true : ((4 * lane) & K) == 0;
+    const bool flip = upper != !asc;  // take the partner's element iff (mine > partner's) != flip
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int tI = lane + 64 * it;
-    const int i = ((tI & ~(J - 1)) << 1) | (tI & (J - 1));  // element with bit J clear; its partner is i + J
-    const bool asc = (i & K) == 0;
+    for (int c = 0; c < 5; ++c)
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      float* q = val + c * 256 + i;
-      const float x = q[0], y = q[J];
-      const bool sw = (x > y) == asc;  // one compare, one scalar xnor with the stage's direction mask, two selects
-      q[0] = sw ? y : x;
-      q[J] = sw ? x : y;
+      for (int r = 0; r < 4; ++r) {
+        const unsigned pk = lane_xor_get<D>(key[c][r]);
+        bool gt;
+        unsigned pi = 0;
+        if (WITH_IDX) {
+          pi = lane_xor_get<D>(ix[c][r]);
+          gt = (((unsigned long long)key[c][r] << 32) | ix[c][r]) > (((unsigned long long)pk << 32) | pi);
+        } else {
+          gt = key[c][r] > pk;
+        }
+        const bool take = gt != flip;
+        key[c][r] = take ? pk : key[c][r];
+        if (WITH_IDX) ix[c][r] = take ? pi : ix[c][r];
+      }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r & J) continue;
+        const int q = r | J;
+        const bool asc = K >= 256 ? true : ((4 * lane + r) & K) == 0;
+        const unsigned a = key[c][r], bb = key[c][q];
+        bool gt;
+        if (WITH_IDX) gt = (((unsigned long long)a << 32) | ix[c][r]) > (((unsigned long long)bb << 32) | ix[c][q]);
+        else gt = a > bb;
+        const bool sw = gt == asc;
+        key[c][r] = sw ? bb : a;
+        key[c][q] = sw ? a : bb;
+        if (WITH_IDX) {
+          const unsigned ia = ix[c][r], ib = ix[c][q];
+          ix[c][r] = sw ? ib : ia;
+          ix[c][q] = sw ? ia : ib;
+        }
+      }
+  }
+}
+template <bool WITH_IDX, int K, int J>
+__device__ __forceinline__ void sortreg_merge(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
+  sortreg_stage<WITH_IDX, K, J>(key, ix, lane);
+  if constexpr (J > 1) sortreg_merge<WITH_IDX, K, J / 2>(key, ix, lane);
+}
+template <bool WITH_IDX, int K>
+__device__ __forceinline__ void sortreg_from(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
+  sortreg_merge<WITH_IDX, K, K / 2>(key, ix, lane);
+  if constexpr (K < 256) sortreg_from<WITH_IDX, K * 2>(key, ix, lane);
+}
+// val [5][256] floats (and idx [5][256] u16, WITH_IDX) in LDS: read as 4 slots per lane, sort, write back in sorted order
+template <bool WITH_IDX>
+__device__ __forceinline__ void sort256_regs(float* val, uint16_t* idx, int lane) {
+  unsigned key[5][4], ix[5][4];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(val + c * 256 + 4 * lane);
+    key[c][0] = sort_key(v.x); key[c][1] = sort_key(v.y); key[c][2] = sort_key(v.z); key[c][3] = sort_key(v.w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ix[c][r] = (unsigned)(4 * lane + r);  // (= what the loader wrote to idx)
+  }
+  sortreg_from<WITH_IDX, 2>(key, ix, lane);
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    *reinterpret_cast<float4*>(val + c * 256 + 4 * lane) =
+        make_float4(sort_unkey(key[c][0]), sort_unkey(key[c][1]), sort_unkey(key[c][2]), sort_unkey(key[c][3]));
+    if (WITH_IDX) {
+      uint2 pk;
+      pk.x = ix[c][0] | (ix[c][1] << 16);
+      pk.y = ix[c][2] | (ix[c][3] << 16);
+      *reinterpret_cast<uint2*>(idx + c * 256 + 4 * lane) = pk;
     }
   }
   __syncthreads();
 }
-template <int K, int J>
-__device__ __forceinline__ void sort256_merge(float* val, int lane) {
-  sort256_stage<K, J>(val, lane);
-  if constexpr (J > 1) sort256_merge<K, J / 2>(val, lane);
-}
-template <int K>
-__device__ __forceinline__ void sort256_from(float* val, int lane) {
-  sort256_merge<K, K / 2>(val, lane);
-  if constexpr (K < 256) sort256_from<K * 2>(val, lane);
-}
-__device__ __forceinline__ void sort256_values(float* val, int lane) { sort256_from<2>(val, lane); }
 
 template <bool WITH_IDX>  // WITH_IDX: carry the original index (stable order + permutation for backward)
 __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
@@ -269,10 +340,8 @@ __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
     }
   }
   __syncthreads();
-  if (!WITH_IDX && P == 256) {
-    // values only, the usual size (64 + 128 samples): the network fully unrolled, so that a pair is ONE ds_read2_b32 / ds_write2_b32
-    // with the partner's distance as an immediate, written back as (min, max) without a branch -- half the LDS instructions
-    sort256_values(val, lane);
+  if (P == 256) {  // the usual size (64 + 128 samples): the whole network in registers
+    sort256_regs<WITH_IDX>(val, idx, lane);
   } else
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
