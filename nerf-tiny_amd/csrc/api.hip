@@ -179,30 +179,49 @@ Weights24 as_w24(const float* const* w) {
 struct Prof {
   std::atomic<bool> on{false};
   std::mutex mu;
-  int cap = 0, used = 0;
-  hipEvent_t* ev = nullptr;  // 2 per launch
+  int cap = 0, used = 0, pool_used = 0;
+  hipEvent_t* ev = nullptr;     // pool: 2 per launch at most
+  hipEvent_t* e0 = nullptr;     // per recorded phase: its start / stop event (handles into the pool)
+  hipEvent_t* e1 = nullptr;
   int* kid = nullptr;
 } g_prof;
+
+// The phases of one API call follow each other without anything launched in between: the stop event of a phase IS the start
+// event of the next one (one event record per boundary instead of two -- each record is a bubble of a few microseconds in front
+// of the next kernel).
+struct ProfChain {
+  hipEvent_t last = nullptr;
+};
 
 struct ProfScope {
   hipStream_t st;
   hipEvent_t stop = nullptr;
-  ProfScope(int kernel_id, hipStream_t s) : st(s) {
+  ProfChain* chain;
+  ProfScope(int kernel_id, hipStream_t s, ProfChain* ch = nullptr) : st(s), chain(ch) {
     if (!g_prof.on.load(std::memory_order_acquire)) return;
     hipEvent_t start = nullptr;
+    bool record_start = false;
     {
       std::lock_guard<std::mutex> lk(g_prof.mu);
       if (g_prof.on.load(std::memory_order_relaxed) && g_prof.used < g_prof.cap) {
         const int slot = g_prof.used++;
         g_prof.kid[slot] = kernel_id;
-        start = g_prof.ev[2 * slot];
-        stop = g_prof.ev[2 * slot + 1];
+        if (chain && chain->last) {
+          start = chain->last;
+        } else {
+          start = g_prof.ev[g_prof.pool_used++];
+          record_start = true;
+        }
+        stop = g_prof.ev[g_prof.pool_used++];
+        g_prof.e0[slot] = start;
+        g_prof.e1[slot] = stop;
       }
     }
-    if (start) (void)hipEventRecord(start, st);
+    if (record_start) (void)hipEventRecord(start, st);
   }
   ~ProfScope() {
     if (stop) (void)hipEventRecord(stop, st);
+    if (chain) chain->last = stop;  // (null when this phase was not recorded: the next one records its own start)
   }
 };
 
@@ -243,9 +262,9 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   const bool bf16x = bf16 && !save && !(flags & NERF_HIP_FORCE_TILE_KERNEL);
   const Weights24 w = as_w24(weights24);
 
-  HIP_TRY(hipMemsetAsync(at<void>(ws, L.status), 0, 256, st));
+  ProfChain pc;  // the phases below follow each other with nothing in between
   if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED)) {
-    ProfScope ps(NERF_HIP_K_PACK, st);
+    ProfScope ps(NERF_HIP_K_PACK, st, &pc);
     if (bf16 && bf16x) HIP_TRY(launch_pack_weights_bf16x(w, at<unsigned char>(ws, L.packed_bf), st));
     else if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
     else HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
@@ -260,7 +279,8 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ra.dvec = at<float>(ws, L.dvec);
   ra.w_dir = w.p[W_DIR]; ra.b_dir = w.p[B_DIR];
   ra.t_c = at<float>(ws, L.t_c);
-  { ProfScope ps(NERF_HIP_K_RAYS, st); HIP_TRY(launch_rays(ra, st)); }
+  ra.status = at<unsigned>(ws, L.status);  // zeroed by the kernel (the later kernels OR their flags into it)
+  { ProfScope ps(NERF_HIP_K_RAYS, st, &pc); HIP_TRY(launch_rays(ra, st)); }
 
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));
@@ -290,7 +310,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   }
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
   auto field = [&](const FieldArgs& f) { return bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
-  { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st); HIP_TRY(field(fa)); }
+  { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st, &pc); HIP_TRY(field(fa)); }
 
   CoarseArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -301,7 +321,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   if (ray0_near_far) { ca.ray0_override = 1; ca.near0 = ray0_near_far[0]; ca.far0 = ray0_near_far[1]; }
   ca.w_c = at<float>(ws, L.w_c); ca.C_coarse = C_coarse; ca.t_f = at<float>(ws, L.t_f);
   ca.status = at<uint32_t>(ws, L.status);
-  { ProfScope ps(NERF_HIP_K_COARSE, st); HIP_TRY(launch_coarse(ca, st)); }
+  { ProfScope ps(NERF_HIP_K_COARSE, st, &pc); HIP_TRY(launch_coarse(ca, st)); }
 
   // fine pass (nerf.py:299), same network (quirk Q10)
   fa.t = at<float>(ws, L.t_f);
@@ -309,7 +329,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.sigma = at<float>(ws, L.sig_f);
   fa.N = Nf; fa.M = B * Nf;
   if (save) { fa.row0 = B * Nc; fa.tile0 = tiles_c; fa.wb0 = (int)wave_blocks(B, Nc); }
-  { ProfScope ps(NERF_HIP_K_FIELD_FINE, st); HIP_TRY(field(fa)); }
+  { ProfScope ps(NERF_HIP_K_FIELD_FINE, st, &pc); HIP_TRY(field(fa)); }
 
   MergeArgs ma;
   memset(&ma, 0, sizeof(ma));
@@ -320,7 +340,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ma.last = last_delta;
   if (save) { ma.bundle = at<float>(ws, L.bundle); ma.w = at<float>(ws, L.w_m); ma.perm = at<uint16_t>(ws, L.perm); }
   ma.C_fine = C_fine;
-  { ProfScope ps(NERF_HIP_K_MERGE, st); HIP_TRY(launch_merge(ma, st)); }
+  { ProfScope ps(NERF_HIP_K_MERGE, st, &pc); HIP_TRY(launch_merge(ma, st)); }
   return NERF_HIP_OK;
 }
 
@@ -328,10 +348,13 @@ int nerf_hip_profile_begin(int max_launches) {
   if (g_prof.ev) return fail(NERF_HIP_ERR_ARG, "profile already active");
   if (max_launches < 1 || max_launches > (1 << 20)) return fail(NERF_HIP_ERR_ARG, "bad max_launches");
   g_prof.ev = new hipEvent_t[2 * (size_t)max_launches];
+  g_prof.e0 = new hipEvent_t[max_launches];
+  g_prof.e1 = new hipEvent_t[max_launches];
   g_prof.kid = new int[max_launches];
   for (int i = 0; i < 2 * max_launches; ++i) HIP_TRY(hipEventCreate(&g_prof.ev[i]));
   g_prof.cap = max_launches;
   g_prof.used = 0;
+  g_prof.pool_used = 0;
   g_prof.on.store(true, std::memory_order_release);
   return NERF_HIP_OK;
 }
@@ -346,16 +369,18 @@ int nerf_hip_profile_end(double* ms_sum, int* count, int n_kernels) {
   int rc = NERF_HIP_OK;
   for (int i = 0; i < g_prof.used; ++i) {
     float ms = 0.f;
-    hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    hipError_t e = hipEventSynchronize(g_prof.e1[i]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof.e0[i], g_prof.e1[i]);
     if (e != hipSuccess) { rc = fail(NERF_HIP_ERR_DEVICE, "profile event: %s", hipGetErrorString(e)); break; }
     const int k = g_prof.kid[i];
     if (k >= 0 && k < n_kernels) { if (ms_sum) ms_sum[k] += ms; if (count) count[k] += 1; }
   }
   for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
   delete[] g_prof.ev;
+  delete[] g_prof.e0;
+  delete[] g_prof.e1;
   delete[] g_prof.kid;
-  g_prof.ev = nullptr; g_prof.kid = nullptr; g_prof.cap = g_prof.used = 0;
+  g_prof.ev = nullptr; g_prof.e0 = g_prof.e1 = nullptr; g_prof.kid = nullptr; g_prof.cap = g_prof.used = g_prof.pool_used = 0;
   return rc;
 }
 
@@ -380,7 +405,8 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   float* save = at<float>(ws, L.save);
   float* G = at<float>(ws, L.G);
   const int wb_c = (int)wave_blocks(B, Nc), wb_tot = wb_c + (int)wave_blocks(B, Nf);
-  if (bf16) { ProfScope ps(NERF_HIP_K_PACK, st); HIP_TRY(launch_pack_weights_bf16_bwd(w, at<unsigned char>(ws, L.packed_bf_bwd), st)); }
+  ProfChain pc;  // the phases below follow each other with nothing in between
+  if (bf16) { ProfScope ps(NERF_HIP_K_PACK, st, &pc); HIP_TRY(launch_pack_weights_bf16_bwd(w, at<unsigned char>(ws, L.packed_bf_bwd), st)); }
 
   // 1. merged composite + per-channel sort backward (nerf.py:302-321)
   MergeBwdArgs mb;
@@ -389,7 +415,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   mb.B = B; mb.Nc = Nc; mb.Nf = Nf; mb.last = last_delta;
   mb.drgb_c = at<float>(ws, L.drgb_c); mb.dsig_c = at<float>(ws, L.dsig_c);
   mb.drgb_f = at<float>(ws, L.drgb_f); mb.dsig_f = at<float>(ws, L.dsig_f); mb.dt_f = at<float>(ws, L.dt_f);
-  { ProfScope ps(NERF_HIP_K_BWD_MERGE, st); HIP_TRY(launch_merge_bwd(mb, st)); }
+  { ProfScope ps(NERF_HIP_K_BWD_MERGE, st, &pc); HIP_TRY(launch_merge_bwd(mb, st)); }
 
   // 2. fine-pass field backward (dX chain incl. d loss / d t_fine)
   FieldBwdArgs fb;
@@ -412,7 +438,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf; fb.wb0 = wb_c;
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
   auto chain = [&](const FieldBwdArgs& f, bool fine) { return bf16 ? launch_field_bwd_bf16(f, fine, st) : tile_kernel ? launch_field_bwd(f, fine, st) : launch_field_bwd_reg(f, fine, st); };
-  { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st); HIP_TRY(chain(fb, true)); }
+  { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st, &pc); HIP_TRY(chain(fb, true)); }
 
   // 3. resampling + coarse composite backward (nerf.py:225-261, 263-281)
   CoarseBwdArgs cb;
@@ -423,17 +449,17 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   cb.B = B; cb.Nc = Nc; cb.Nf = Nf;
   if (ray0_near_far) { cb.ray0_override = 1; cb.near0 = ray0_near_far[0]; cb.far0 = ray0_near_far[1]; }
   cb.drgb_c = at<float>(ws, L.drgb_c); cb.dsig_c = at<float>(ws, L.dsig_c);
-  { ProfScope ps(NERF_HIP_K_BWD_COARSE, st); HIP_TRY(launch_coarse_bwd(cb, st)); }
+  { ProfScope ps(NERF_HIP_K_BWD_COARSE, st, &pc); HIP_TRY(launch_coarse_bwd(cb, st)); }
 
   // 4. coarse-pass field backward
   fb.t = at<float>(ws, L.t_c); fb.rgb = at<float>(ws, L.rgb_c);
   fb.drgb = at<float>(ws, L.drgb_c); fb.dsig = at<float>(ws, L.dsig_c); fb.dt = nullptr;
   fb.row0 = 0; fb.tile0 = 0; fb.N = Nc; fb.M = B * Nc; fb.wb0 = 0;
-  { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st); HIP_TRY(chain(fb, false)); }
+  { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st, &pc); HIP_TRY(chain(fb, false)); }
 
   // 5. weight gradients: dW = G^T X over all B*(Nc+Nf) samples
   if (bf16) {
-    ProfScope ps(NERF_HIP_K_BWD_DW, st);
+    ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
     const unsigned char* bs = at<unsigned char>(ws, L.bsave);
     const unsigned char* bg = at<unsigned char>(ws, L.bG);
     float* slabs = at<float>(ws, L.bslabs);
@@ -469,7 +495,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR], st));
     HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA], st));
   } else {
-    ProfScope ps(NERF_HIP_K_BWD_DW, st);
+    ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
     DwBatch batch;
     build_dw_batch(batch, G, save, at<float>(ws, L.dz), MS, dw);
     float* slabs = at<float>(ws, L.slabs);

@@ -71,6 +71,7 @@ struct RaysArgs {
   float* t_c;        // [B][Nc] or null
   float* d_cam;      // [B][3] or null
   float* d_wrd;      // [B][3] or null
+  unsigned* status;  // the workspace's 64 status words, zeroed here (first kernel of a forward), or null
 };
 
 struct CoarseArgs {
