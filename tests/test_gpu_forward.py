@@ -343,6 +343,33 @@ def test_exact_ties_in_the_sorted_channels_do_not_change_the_forward(oracle, pkg
     assert max_rel(w, ow) < 1e-5 and max_rel(C_f, oracle.composite(ow, sb[:, :, 1:4])) < 1e-5
 
 
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (32, 64), (16, 32)])
+def test_merge_sort_network_on_adversarial_values(oracle, pkg, dev, Nc, Nf):
+    """The five per-channel sorts against torch.sort on values the renderer never produces but a sort must order anyway: negative
+    numbers, both zeros, runs of duplicates, huge and tiny magnitudes.  64 + 128 samples run the register network (256 slots, keys =
+    order-preserving unsigned images of the floats), the smaller counts the LDS network."""
+    B = 96
+    gen = torch.Generator().manual_seed(Nc)
+    N = Nc + Nf
+
+    def channel():
+        x = torch.randn(B, N, generator=gen) * torch.tensor([1e-30, 1.0, 1e30])[torch.randint(0, 3, (B, N), generator=gen)]
+        x = torch.where(torch.rand(B, N, generator=gen) < 0.2, torch.round(x.clamp(-3, 3)), x)          # duplicates, +0 and -0
+        x = torch.where(torch.rand(B, N, generator=gen) < 0.05, -torch.zeros(B, N), x)
+        return x
+
+    ch = [channel() for _ in range(5)]
+    t_all, r, g, b, sg = ch
+    d = lambda x: x.contiguous().to(dev)
+    rgb = torch.stack((r, g, b), dim=2)
+    bundle, w, C_f = pkg.ops.merge_composite(d(t_all[:, :Nc]), d(t_all[:, Nc:]), d(sg[:, :Nc]), d(sg[:, Nc:]), d(rgb[:, :Nc]), d(rgb[:, Nc:]))
+    ob = torch.cat((t_all.unsqueeze(2), rgb, sg.unsqueeze(2)), dim=2)
+    sb, _ = torch.sort(ob, dim=1)
+    got = bundle.cpu()
+    assert torch.equal(got, sb)  # (== on values: a -0 and a +0 may trade places)
+    assert bool(torch.isfinite(got).all())
+
+
 def test_near_equal_far_is_flagged_where_the_reference_exits(oracle, pkg, dev):
     """near == far (nerf.py:288: numpy.linspace with step == 0).  numpy then evaluates (i / div) * delta for EVERY ray of the
     batch instead of i * step -- one ulp different for the other rays -- which the kernels do not reproduce; it cannot be
