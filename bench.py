@@ -15,6 +15,11 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     batches -- image-space ray batches are independent units, so the data path has no collective: scaling = "weak".
     The train legs add the one real exchange of the path, a SUM all-reduce of the 593,924 fp32 gradients (2.27 MiB) in one
     flat bucket the backward kernels write straight into; its measured time is reported (`allreduce_ms`).
+    The same line also carries the STRONG-scaling form of the legs (`extra.strong_*`: one 4096-ray batch split 4096/N, the global
+    ray 0's spacing forwarded to every shard, each with its `allreduce_ms`) -- north_star's ">= 6x strong scaling to 8 GPUs".
+  * N = 1: `per_rank_proxy` times what one rank of that 8-GPU job does with its share (512 rays; and the reference's default batch of
+    400 rays, conf/lego.ini:7) + a single-rank RCCL all-reduce, and reports `implied_strong_scaling_8 = t(4096) / (t(512) + allreduce)`.
+  * `parity`: the timed configuration rendered once on the golden cfg2 fixture against the REFERENCE's own outputs (max-rel, PSNR).
   * `n_gpus` in the line is `dist.get_world_size()`, not the flag.
 Rank 0 prints ONE JSON line.
 """
@@ -86,12 +91,13 @@ def launch_ranks(n, argv):
 # --------------------------------------------------------------------------------------------------------------------
 # synthetic workload
 # --------------------------------------------------------------------------------------------------------------------
-def synth_inputs(seed):
+def synth_inputs(seed, B=None):
     """cfg2: row, col ~ U{0..399}, one lego-like pose, near/far 2/6.  Pure numpy/torch; the
     same generator as oracle.lego_inputs, restated here so the product path never imports the oracle."""
     import numpy as np
     import torch
 
+    B = globals()["B"] if B is None else B
     H = W = 400
     angle = 0.6911112070083618
     focal = 0.5 * W / np.tan(0.5 * angle)
@@ -109,8 +115,9 @@ def synth_inputs(seed):
             torch.from_numpy(C_true))
 
 
-def synth_weights(seed):
-    """random-init weights of the reference architecture: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) per tensor."""
+def synth_weights(seed, sharp=False):
+    """random-init weights of the reference architecture: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) per tensor (`sharp`: sigma layer x50,
+    a peaky density like a trained scene's: the golden fixtures' second weight set)."""
     import math
 
     import numpy as np
@@ -123,7 +130,10 @@ def synth_weights(seed):
     for i, (k, v) in enumerate(sd.items()):
         fan_in = v.shape[1] if v.dim() == 2 else sd[k.replace("bias", "weight")].shape[1]
         bound = 1.0 / math.sqrt(fan_in)
-        sd[k] = torch.from_numpy(np.random.default_rng([seed, i]).uniform(-bound, bound, size=tuple(v.shape)).astype(np.float32))
+        w = np.random.default_rng([seed, i]).uniform(-bound, bound, size=tuple(v.shape)).astype(np.float32)
+        if sharp and "sigma_layer" in k:
+            w = w * np.float32(50.0)
+        sd[k] = torch.from_numpy(w)
     m.load_state_dict(sd)
     return m
 
@@ -144,9 +154,10 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=12.0):
     """The oracle (bit-identical restatement of the reference, 'port') timed on this box's host cores on the SAME
-    cfg2 workload: one warm-up + as many full 4096-ray forwards as fit the budget (>= 1), best time."""
+    cfg2 workload: one warm-up + as many full 4096-ray forwards as fit the budget (>= 1, <= 3), best time; then the train step
+    (forward + loss + backward) on a 1024-ray subset of the same batch, best of 2."""
     import torch
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -154,12 +165,12 @@ def cpu_baseline(seconds_budget=25.0):
 
     cores = host_cores()
     torch.set_num_threads(cores)
-    row, col, pb, K, _ = O.lego_inputs(B, seed=0)
+    row, col, pb, K, C_true = O.lego_inputs(B, seed=0)
     params = O.make_weights(0)
     with torch.no_grad():
         O.render(params, row[:256], col[:256], pb[:256], K, NC, NF)  # warm-up (small)
         best, n, t_start = None, 0, time.perf_counter()
-        while n < 1 or (time.perf_counter() - t_start) < seconds_budget and n < 5:
+        while n < 1 or (time.perf_counter() - t_start) < seconds_budget and n < 3:
             t0 = time.perf_counter()
             O.render(params, row, col, pb, K, NC, NF)
             dt = time.perf_counter() - t0
@@ -175,6 +186,18 @@ def cpu_baseline(seconds_budget=25.0):
             O.render(params, row, col, pb, K, NC, NF)
             out["value_at_8_threads"] = round(B / (time.perf_counter() - t0), 1)
         torch.set_num_threads(cores)
+    # train step: forward + loss + backward of the oracle (autograd) on the first 1024 rays of the batch (the full batch needs
+    # 12 GB and ~15 s per step; BASELINE.md section 2: 273 rays/s at B = 1024 vs 194 at B = 4096 on 8 Xeon vCPUs)
+    bt = 1024
+    tb = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        O.loss_and_grads(params, row[:bt], col[:bt], pb[:bt], K, C_true[:bt], NC, NF)
+        dt = time.perf_counter() - t0
+        tb = dt if tb is None else min(tb, dt)
+    out["train"] = {"value": round(bt / tb, 1), "unit": "rays/s", "cores": cores, "kind": "port",
+                    "sample": f"forward + loss + backward (torch autograd, CPU fp32) of the first {bt} rays x (64+128) of the same batch, "
+                              f"best of 2; {tb:.2f} s"}
     return out
 
 
@@ -229,6 +252,8 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
                 if timed:
                     e1.record()
                     ar_events.append((e0, e1))
+            elif bucket is not None:
+                bucket.consume()  # no collective in this run: the gradients count as used
         else:
             with torch.no_grad():
                 model(row, col, pb, K)
@@ -316,7 +341,7 @@ DW_BF16_KIB_PER_WAVE_BLOCK = 318  # G and X pieces of bf16_common.h over the 11 
 
 
 def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong):
-    rays = (B if strong else B * world) * steps
+    rays = b_local * world * steps  # strong: b_local = B / world
     value = rays / elapsed
     flop_ray = FLOP_PER_RAY_TRAIN if leg.train else FLOP_PER_RAY_FWD
     roof, phases = rooflines(leg, prof, b_local, steps)
@@ -334,6 +359,41 @@ def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong)
         rep["allreduce"] = (f"one flat SUM all-reduce of {N_PARAMS} fp32 gradients (2.27 MiB) over RCCL, world {world}" if ar_ms is not None
                             else "none (single rank without a process group)")
     return rep
+
+
+def parity_block(model, dev):
+    """One render of the golden cfg2 case (4096 rays of the 400x400 lego-like view, 64 + 128 samples) with the library, against the
+    outputs the REFERENCE itself produced for these inputs and weights (stored in the fixture by tests/golden/make_golden.py, which
+    imports /root/reference/nerf.py in the build container).  fp32: the headline path; bf16: the cfg3 variant against the same fp32
+    reference outputs.  No oracle code runs here: the fixture is data."""
+    import numpy as np
+    import torch
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cfg2_lego_rand4096.npz"))
+    assert int(g["Nc"]) == NC and int(g["Nf"]) == NF and g["row"].shape[0] == B
+    m = synth_weights(int(g["seed"]), bool(g["sharp"])).to(dev)  # the fixture stores the generator seed, not the weights
+    row, col, pbd = torch.from_numpy(g["row"]).to(dev), torch.from_numpy(g["col"]).to(dev), torch.from_numpy(g["poses_bound"]).float().to(dev)
+    K = torch.from_numpy(g["K_inv"])
+    ref_c, ref_f = torch.from_numpy(g["C_coarse"]).double(), torch.from_numpy(g["C_fine"]).double()
+
+    def errs(Cc, Cf):
+        Cc, Cf = Cc.double().cpu(), Cf.double().cpu()
+        mse = float(((Cf - ref_f) ** 2).mean())
+        return {"max_rel_C_coarse": float((Cc - ref_c).abs().max() / ref_c.abs().max()), "max_rel_C_fine": float((Cf - ref_f).abs().max() / ref_f.abs().max()),
+                "max_elementwise_rel_C_fine": float(((Cf - ref_f).abs() / ref_f.abs().clamp_min(1e-6)).max()),
+                "psnr_vs_ref_db": round(10.0 * float(np.log10(1.0 / max(mse, 1e-300))), 2)}
+
+    out = {"fixture": "cfg2_lego_rand4096", "reference": "outputs of /root/reference/nerf.py on the same inputs and weights (tests/golden/make_golden.py)",
+           "bar": "max_rel <= 1e-4 (fp32)"}
+    with torch.no_grad():
+        out.update(errs(*m(row, col, pbd, K)))
+        m.bf16_mlp = True
+        out["bf16_mlp_vs_fp32_reference"] = errs(*m(row, col, pbd, K))
+    out["pass"] = bool(out["max_rel_C_coarse"] <= 1e-4 and out["max_rel_C_fine"] <= 1e-4)
+    for k in ("max_rel_C_coarse", "max_rel_C_fine", "max_elementwise_rel_C_fine"):
+        out[k] = float(f"{out[k]:.3e}")
+        out["bf16_mlp_vs_fp32_reference"][k] = float(f"{out['bf16_mlp_vs_fp32_reference'][k]:.3e}")
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -426,32 +486,112 @@ def main():
     strong = args.scaling == "strong"
     row, col, pb, K, C_true = synth_inputs(seed=1000 + (0 if strong else rank))
     model = synth_weights(seed=0).to(dev)
+    # the flat gradient buffer of the data-parallel trainer: the backward kernels write into views of it (no pack / unpack)
+    bucket = P.parallel.GradBucket(model.network.parameters())
+
+    def shard(full, lo, hi):
+        """Device inputs of rays [lo, hi) of a batch; the model is told its batch size and the GLOBAL ray 0's (near, far): its
+        coarse spacing goes to every shard (nerf.py:233, quirk Q6)."""
+        r, c, p_, ct = full
+        model.batch_ray = hi - lo
+        model.ray0_near_far = (float(p_[0, 15]), float(p_[0, 16])) if lo > 0 else None
+        return (r[lo:hi].to(dev), c[lo:hi].to(dev), p_[lo:hi].float().to(dev), ct[lo:hi].to(dev))
+
+    full = (row, col, pb, C_true)
     b_local = B
     if strong:
         if B % world:
             raise SystemExit(f"--scaling strong needs {B} % N == 0")
         b_local = B // world
-        sl = slice(rank * b_local, (rank + 1) * b_local)
-        ray0 = (float(pb[0, 15]), float(pb[0, 16]))  # the GLOBAL ray 0's spacing goes to every shard (nerf.py:233)
-        row, col, pb, C_true = row[sl], col[sl], pb[sl], C_true[sl]
-        model.batch_ray = b_local
-        model.ray0_near_far = ray0
-    inputs = (row.to(dev), col.to(dev), pb.float().to(dev), C_true.to(dev))
-    # the flat gradient buffer of the data-parallel trainer: the backward kernels write into views of it (no pack / unpack)
-    bucket = P.parallel.GradBucket(model.network.parameters())
+    inputs = shard(full, rank * b_local, (rank + 1) * b_local) if strong else shard(full, 0, B)
 
     head = Leg("headline", args.mode == "train", args.mlp == "bf16")
     elapsed, prof, ar_ms = run_leg(head, model, inputs, K, args.steps, args.warmup, dist, dev, bucket)
     rep = leg_report(head, elapsed, prof, ar_ms, args.steps, args.warmup, world, b_local, strong)
     extra = {}
+    legs = (("forward_f32", False, False, 20, 3), ("train_f32", True, False, 8, 2), ("forward_bf16", False, True, 50, 5), ("train_bf16", True, True, 20, 3))
     if not args.no_extra:
-        for name, train, bf16, k, w in (("forward_f32", False, False, 20, 3), ("train_f32", True, False, 8, 2),
-                                        ("forward_bf16", False, True, 50, 5), ("train_bf16", True, True, 20, 3)):
+        for name, train, bf16, k, w in legs:
             if (train, bf16) == (head.train, head.bf16):
                 continue
             leg = Leg(name, train, bf16)
             e, p, a = run_leg(leg, model, inputs, K, k, w, dist, dev, bucket)
             extra[name] = leg_report(leg, e, p, a, k, w, world, b_local, strong)
+
+    def brief(r, rays_per_step):
+        return {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "kernel_ms_per_step", "allreduce_ms") if k in r} | {
+            "rays_per_step": rays_per_step, "roofline_frac": r["roofline"]["frac"], "whole_path_frac_of_mfma_peak": r["whole_path_frac_of_mfma_peak"]}
+
+    # ---- N > 1: the STRONG-scaling form of the same legs in the same line (north_star: ">= 6x strong scaling to 8 GPUs"): ONE 4096-ray
+    # batch (the same on every rank) split into contiguous slices of 4096 / N rays, the global ray 0's spacing forwarded, one flat SUM
+    # all-reduce per train step where the reference has loss.backward(); optimizer.step() (nerf.py:473-474)
+    if world > 1 and not strong and not args.no_extra and B % world == 0:
+        g_full = synth_inputs(seed=1000)
+        g_full = (g_full[0], g_full[1], g_full[2], g_full[4])
+        bs = B // world
+        s_in = shard(g_full, rank * bs, (rank + 1) * bs)
+        for name, train, bf16, k, w in legs:
+            leg = Leg(name, train, bf16)
+            e, p, a = run_leg(leg, model, s_in, K, 3 * k, w + 2, dist, dev, bucket)
+            extra["strong_" + name] = brief(leg_report(leg, e, p, a, 3 * k, w + 2, world, bs, True), B)
+        inputs = shard(full, 0, B)
+
+    # ---- N = 1: what ONE rank of an 8-GPU strong-scaling job does with its share, measured here: 512 rays (4096 / 8) and the reference's
+    # own default batch of 400 rays (conf/lego.ini:7), the first rays of the same batch (global ray 0 = local ray 0)
+    proxy = None
+    if world == 1 and not strong and not args.no_extra:
+        proxy = {}
+        t_full = {name: (rep["ms_per_step"] if (train, bf16) == (head.train, head.bf16) else extra[name]["ms_per_step"]) for name, train, bf16, _, _ in legs}
+        for bs in (512, 400):
+            s_in = shard(full, 0, bs)
+            proxy[str(bs)] = {}
+            for name, train, bf16, k, w in legs:
+                leg = Leg(name, train, bf16)
+                kk = 4 * k
+                e, p, a = run_leg(leg, model, s_in, K, kk, w + 3, dist, dev, bucket)
+                proxy[str(bs)][name] = brief(leg_report(leg, e, p, a, kk, w + 3, 1, bs, True), bs)
+        inputs = shard(full, 0, B)
+        # the collective a rank adds per train step, measured on a REAL (single-rank) RCCL group: launch + kernel latency of one flat
+        # 2.27 MiB SUM all-reduce, without the xGMI hops an 8-rank ring adds (those are the driver's 8-GPU run to measure)
+        ar1 = None
+        try:
+            if dist is None:
+                sys.stdout.flush()
+                saved_stdout = os.dup(1)
+                os.dup2(2, 1)
+                import torch.distributed as dist
+
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+                dist.init_process_group("nccl", device_id=dev)
+            for _ in range(5):
+                bucket.allreduce_sum()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                bucket.allreduce_sum()
+            e1.record()
+            torch.cuda.synchronize()
+            ar1 = e0.elapsed_time(e1) / 50
+        except Exception as ex:  # no RCCL on this box: the proxy then carries no collective
+            print(f"bench.py: single-rank RCCL all-reduce not measured: {ex}", file=sys.stderr)
+        proxy["allreduce_ms_single_rank"] = None if ar1 is None else round(ar1, 4)
+        proxy["implied_strong_scaling_8"] = {
+            name: round(t_full[name] / (proxy["512"][name]["ms_per_step"] + ((ar1 or 0.0) if train else 0.0)), 2) for name, train, _, _, _ in legs}
+        proxy["note"] = ("t(4096 rays) / (t(512 rays) + single-rank all-reduce for the train legs), all measured in this run on one GPU; "
+                         "the 8-GPU number itself is extra.strong_* of the driver's N = 8 line")
+
+    # ---- parity of the timed configuration, in the line: the reference's OWN outputs for cfg2 (tests/golden/cfg2_lego_rand4096.npz: inputs,
+    # weight seed and the C_coarse / C_fine the reference returned in the build container) against this library's render of the same
+    parity = None
+    if rank == 0 and not args.no_extra:
+        try:
+            parity = parity_block(model, dev)
+        except Exception as ex:
+            parity = {"error": str(ex)}
 
     if rank == 0:
         out = {
@@ -471,12 +611,19 @@ def main():
         for k in ("roofline_phases", "allreduce_ms", "allreduce"):
             if k in rep:
                 out[k] = rep[k]
+        if parity is not None:
+            out["parity"] = parity
         if extra:
             out["extra"] = extra
+        if proxy is not None:
+            out["per_rank_proxy"] = proxy
+            out["implied_strong_scaling_8"] = proxy["implied_strong_scaling_8"]
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = round(rep["value"] / cb["value"], 1)
+            if "train_f32" in extra and "train" in cb:
+                out["gpu_over_cpu_train"] = round(extra["train_f32"]["value"] / cb["train"]["value"], 1)
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)

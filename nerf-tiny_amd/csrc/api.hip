@@ -45,6 +45,9 @@ int next_pow2(int n) {
 int check_sizes(int B, int Nc, int Nf) {
   if (B < 2) return fail(NERF_HIP_ERR_ARG, "B=%d: the reference needs B >= 2 (nerf.py:208 .squeeze())", B);
   if (Nc < 2 || Nc > 1024 || Nf < 1 || Nf > 1024) return fail(NERF_HIP_ERR_ARG, "Nc=%d Nf=%d outside 2..1024 / 1..1024", Nc, Nf);
+  // the kernels index samples (rows of the saved tensors, tiles, wave blocks) with 32-bit integers
+  if ((long long)B * (Nc + Nf) + DUMP_ROWS + 256 >= (1ll << 31))
+    return fail(NERF_HIP_ERR_ARG, "B=%d x (Nc + Nf = %d) samples: a batch must stay below 2^31 samples", B, Nc + Nf);
   return NERF_HIP_OK;
 }
 

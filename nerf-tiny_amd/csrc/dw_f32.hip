@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void k_dw_thin(const DwItem p, const long l
   constexpr int nblocks = 2, msubs = DW_WAVES / nblocks;
   const int blk = wv % nblocks, msub = wv / nblocks;
   const int gran = DW_ROWS * DW_STAGES * msubs;
-  const int Mrows = (int)Mtot;  // < 2^31 rows and < 4 GiB per operand (checked by the host)
+  const int Mrows = (int)Mtot;  // < 2^31 rows (api.hip: check_sizes); operand addresses are 64-bit
   const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran;
   const int per_wave = per_wg / msubs;  // a multiple of the 24 rows of one pipeline round
   const long long r_begin64 = (long long)lw * per_wg + (long long)msub * per_wave;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
   const int msubs = 4 / nblocks;
   const int blk = wv % nblocks, msub = wv / nblocks;
   const int gran = 2 * DW4_DEPTH * msubs;
-  const int Mrows = (int)Mtot;  // < 2^31 rows and < 4 GiB per operand (checked by the host)
+  const int Mrows = (int)Mtot;  // < 2^31 rows (api.hip: check_sizes); operand addresses are 64-bit
   const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran;
   const int per_wave = per_wg / msubs;  // a multiple of the 2 DW4_DEPTH rows of one ring round
   const long long r_begin64 = (long long)lw * per_wg + (long long)msub * per_wave;

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_coarse(const CoarseArgs a) {
 // the 15 stages with partner distance 1 or 2 are lane-local and the 21 others exchange with lane l ^ (distance / 4) through DPP
 // (distance 4, 8), ds_swizzle (16 .. 64) or one permute (128) -- no LDS traffic between stages and no barriers (the LDS version
 // spent 36 barriers and ~500 two-address LDS instructions per ray).  Keys are the floats' order-preserving unsigned images
-// (sign flipped for positives, all bits for negatives: -0 sorts just below +0, otherwise the order of torch.sort); WITH_IDX carries
+// (sign flipped for positives, all bits for negatives; -0 keyed as +0 and NaN as the maximum: the order of torch.sort); WITH_IDX carries
 // the original slot as the low half of a 64-bit key, which makes the order total (= a stable sort, as before).
 template <int D>
 __device__ __forceinline__ unsigned lane_xor_get(unsigned v) {  // v of lane (l ^ D)
@@ -225,8 +225,12 @@ __device__ __forceinline__ unsigned lane_xor_get(unsigned v) {  // v of lane (l 
   else if constexpr (D < 32) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (D << 10));   // bit-mask mode: xor D inside 32 lanes
   else return (unsigned)__shfl_xor((int)v, 32);
 }
+// torch.sort's order: -0 and +0 compare equal (both map to +0's key; the original index breaks the tie, as everywhere), every NaN
+// sorts last (the maximum key, above the +inf padding).
 __device__ __forceinline__ unsigned sort_key(float x) {
-  const unsigned b = __float_as_uint(x);
+  unsigned b = __float_as_uint(x);
+  if ((b & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;  // NaN of either sign
+  if (b == 0x80000000u) b = 0u;                              // -0 -> +0
   return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 __device__ __forceinline__ float sort_unkey(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
       const size_t g = (size_t)ray * a.Nf + (i - a.Nc);
       v[0] = a.t_f[g]; v[1] = a.rgb_f[g * 3]; v[2] = a.rgb_f[g * 3 + 1]; v[3] = a.rgb_f[g * 3 + 2]; v[4] = a.sig_f[g];
     } else {
-      v[0] = v[1] = v[2] = v[3] = v[4] = INFINITY;
+      v[0] = v[1] = v[2] = v[3] = v[4] = __builtin_nanf("");  // padding = the maximum key: behind every real value, NaNs included
     }
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
@@ -355,14 +359,16 @@ __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
           const float x = val[c * P + i], y = val[c * P + l];
           if (WITH_IDX) {
             const uint16_t xi = idx[c * P + i], yi = idx[c * P + l];
-            const bool gt = (x > y) || (x == y && xi > yi);
+            const unsigned kx = sort_key(x), ky = sort_key(y);  // the register network's order: +-0 equal, NaN last
+            const bool gt = (kx > ky) || (kx == ky && xi > yi);
             if (gt == asc) {
               val[c * P + i] = y; val[c * P + l] = x;
               idx[c * P + i] = yi; idx[c * P + l] = xi;
             }
           } else {  // values only: equal keys are interchangeable
-            const bool gt = x > y;
-            if (gt == asc && x != y) {
+            const unsigned kx = sort_key(x), ky = sort_key(y);
+            const bool gt = kx > ky;
+            if (gt == asc && kx != ky) {
               val[c * P + i] = y; val[c * P + l] = x;
             }
           }

@@ -101,6 +101,7 @@ class _RenderFn(torch.autograd.Function):
             ctx.generation = gen
             ctx.model, ctx.ws, ctx.flags, ctx.B = model, ws, flags, B
             ctx.params, ctx.ray0 = params, ray0
+            ctx.bucket = model.grad_bucket  # bound when the graph is recorded: toggling model.grad_bucket later does not change this step
         return C_c, C_f
 
     @staticmethod
@@ -109,11 +110,17 @@ class _RenderFn(torch.autograd.Function):
         if ctx.generation != model._ws_generation.get(ctx.flags):
             raise RuntimeError("the workspace of this forward was reused by a later training forward; call backward first")
         params = ctx.params
-        bucket = model.grad_bucket
+        bucket = ctx.bucket
         if bucket is not None:
-            # data-parallel trainer: the kernels write straight into views of the flat all-reduce buffer (parallel.GradBucket)
+            # data-parallel trainer: the kernels write straight into views of the flat all-reduce buffer (parallel.GradBucket).
+            # Overwrite semantics: ONE backward per step.  torch.autograd.grad, parameter hooks, gradient accumulation and a second
+            # loss through the same model are not supported in bucket mode (they would see None / overwritten gradients).
             if len(bucket.params) != len(params) or any(a is not b for a, b in zip(bucket.params, params)):
                 raise RuntimeError("model.grad_bucket was built for other parameters")
+            if bucket.pending:
+                raise RuntimeError("a second backward would overwrite the gradients of the previous one in model.grad_bucket before "
+                                   "they were used: call bucket.allreduce_sum() / the optimizer step (or bucket.consume()) first")
+            bucket.pending = True
             grads = bucket.views
         else:
             grads = [torch.empty_like(p) for p in params]
@@ -150,8 +157,9 @@ class NeRFModel(nn.Module):
         self.force_tile_kernel = False
         #: BASELINE.json cfg3: run the MLP on bf16 MFMA (fp32 accumulation, fp32 everything else); ~1e-2 of the fp32 result
         self.bf16_mlp = False
-        #: parallel.GradBucket or None.  When set, backward writes the 24 gradients straight into the bucket's flat buffer and
-        #: makes p.grad its views (overwrite semantics: one backward per step), so the all-reduce needs no pack / unpack
+        #: parallel.GradBucket or None.  When set (read when the forward records the graph), backward writes the 24 gradients straight
+        #: into the bucket's flat buffer and makes p.grad its views (overwrite semantics: one backward per step, a second one before
+        #: the gradients were consumed raises; autograd.grad / hooks unsupported), so the all-reduce needs no pack / unpack
         self.grad_bucket = None
         self._ws = {}            # flags -> (key, workspace): one slot per flag set (training / inference / bf16 ...)
         self._ws_generation = {}  # flags -> count of training forwards on that slot

@@ -47,6 +47,14 @@ class GradBucket:
         self.numel = sum(p.numel() for p in self.params)  # 593,924 real gradients; the padding stays zero
         self.flat = torch.zeros(o, dtype=p0.dtype, device=p0.device)
         self.views = [self.flat[a:a + p.numel()].view_as(p) for a, p in zip(offs, self.params)]
+        #: a backward has written gradients into the views that nothing has consumed yet (all-reduce / optimizer step).  A second
+        #: backward into the same bucket would OVERWRITE them (the kernels store, they do not accumulate): _RenderFn.backward raises.
+        self.pending = False
+
+    def consume(self):
+        """The gradients in the views have been used (optimizer step, all-reduce, or deliberately dropped): the next backward may
+        overwrite them.  `allreduce_sum` and `train.FusedAdam.step` call this."""
+        self.pending = False
 
     def _foreign(self):
         return [(v, p) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
@@ -63,6 +71,7 @@ class GradBucket:
         self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.unpack()
+        self.consume()
 
 
 def train_step_sharded(model, bucket: GradBucket, row, col, poses_bound, K_inv, C_true, rank: int, world: int, group=None):
@@ -82,6 +91,8 @@ def train_step_sharded(model, bucket: GradBucket, row, col, poses_bound, K_inv, 
         model.ray0_near_far, model.grad_bucket = prev_ray0, prev_bucket
     if world > 1 or (dist.is_available() and dist.is_initialized()):
         bucket.allreduce_sum(group)
+    else:
+        bucket.consume()  # a single process without a group: p.grad (the views) go straight to the optimizer
     return C_c, C_f, loss
 
 
@@ -135,12 +146,25 @@ def render_rows_sharded(model, row, col, poses_bound, K_inv, rank: int, world: i
     return lo, hi, C
 
 
-def gather_rows(C_local: torch.Tensor, n_total: int, rank: int, world: int, group=None, bounds=None) -> torch.Tensor:
-    """Assemble the full [n_total, 3] picture on every rank (outside the timed data path).  `bounds`: list of every rank's
-    (lo, hi) when the shards are not `shard_bounds` (e.g. `batch_shard_bounds`)."""
+def gather_rows(C_local: torch.Tensor, n_total: int, rank: int, world: int, group=None, bounds=None, batch: int | None = None) -> torch.Tensor:
+    """Assemble the full [n_total, 3] picture on every rank (outside the timed data path).  The shards must be the ones the rows
+    were rendered with: `batch` = model.batch_ray for the output of `render_rows_sharded` with its default `align_to_batches`
+    (shards on the reference's batch grid, `batch_shard_bounds`); `bounds` = an explicit list of every rank's (lo, hi); neither =
+    plain `shard_bounds`.  A local shard of another length than this rank's entry is an error, never silently misplaced."""
+    if bounds is not None and batch is not None:
+        raise ValueError("gather_rows: give `bounds` or `batch`, not both")
+    if bounds is not None:
+        sizes = list(bounds)
+    elif batch is not None:
+        sizes = [batch_shard_bounds(n_total, batch, r, world) for r in range(world)]
+    else:
+        sizes = [shard_bounds(n_total, r, world) for r in range(world)]
+    lo, hi = sizes[rank]
+    if C_local.shape[0] != hi - lo:
+        raise ValueError(f"gather_rows: rank {rank} holds {C_local.shape[0]} rows but its shard [{lo}, {hi}) has {hi - lo}: pass the "
+                         "`batch` (or `bounds`) the rows were rendered with")
     if world == 1:
         return C_local
-    sizes = bounds if bounds is not None else [shard_bounds(n_total, r, world) for r in range(world)]
     mx = max(h - l for l, h in sizes)
     pad = torch.zeros(mx, 3, dtype=C_local.dtype, device=C_local.device)
     pad[: C_local.shape[0]] = C_local

@@ -12,22 +12,25 @@ row, col, pb, K, Ct = bench.synth_inputs(1000)
 m = bench.synth_weights(0).to(dev)
 m.force_tile_kernel = os.environ.get("NERF_STAMP_TILE") == "1"
 row, col, pb = row.to(dev), col.to(dev), pb.float().to(dev)
+flags = _abi.FORCE_TILE_KERNEL if m.force_tile_kernel else 0
 with torch.no_grad():
     m(row, col, pb, K)
-    ws = m.last_workspace
-    st = ws[:256].view(torch.int64)
-    st[8:16] = 0
+    # the stamps live in the workspace's 'dbg' area (words 0..31 = forward: phase sums 0..7, tile count at 31), as in train_stamps.py
+    dbg = _abi.ws_view(m.last_workspace, bench.B, bench.NC, bench.NF, flags, "dbg", (32,), torch.int64)
+    dbg.zero_()
     m(row, col, pb, K)
     torch.cuda.synchronize()
-    v = st[8:16].cpu().tolist()
+    v = dbg.cpu().tolist()
 tile = os.environ.get("NERF_STAMP_TILE") == "1"  # set together with model.force_tile_kernel
 if tile:
     names = ["encode/prologue", "mfma loops", "barrier after mfma", "acc_store", "barrier after store", "heads+rest"]
     ideal = [0, 4608 * 64, 0, 0, 0, 0]
 else:
-    names = ["prologue (loads, point, encode)", "layers 0..7", "sigma head", "point_info + dir_info", "colour head + stores"]
-    ideal = [0, 8320 * 64, 0, 1544 * 64, 0]
-n = v[7]; tot = sum(v[:len(names)])
+    names = ["prologue (loads, point, encode)", "layer 0", "layers 1-3", "layer 4", "layers 5-7", "sigma head", "point_info + dir_info", "colour head + stores"]
+    ideal = [0, 264 * 64, 3096 * 64, 1288 * 64, 3096 * 64, 0, 1544 * 64, 0]
+n = v[7] if tile else v[31]; tot = sum(v[:len(names)])  # (the LDS-tile kernel keeps its count at word 7)
+if n == 0:
+    raise SystemExit("no stamps recorded: run with NERF_HIP_LIB=nerf-tiny_amd/libnerf_hip_stamps.so (make -C nerf-tiny_amd/csrc stamps)")
 print("tiles", n, "cycles/tile", tot / n)
 for nm, x, idl in zip(names, v, ideal):
     extra = f"  (MFMA issue time {idl})" if idl else ""

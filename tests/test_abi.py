@@ -33,6 +33,10 @@ def test_ws_bytes_and_errors(pkg):
         pkg._abi.ws_bytes(1, 64, 128, 0)  # B = 1 is unsupported like the reference (quirk Q7)
     with pytest.raises(pkg._abi.NerfHipError):
         pkg._abi.ws_bytes(8, 1, 128, 0)
+    # the kernels index samples with 32-bit integers: a batch of >= 2^31 samples is refused, not wrapped
+    with pytest.raises(pkg._abi.NerfHipError, match="2\\^31"):
+        pkg._abi.ws_bytes(2_000_000, 1024, 1024, pkg._abi.SAVE_FOR_BACKWARD)
+    assert pkg._abi.ws_bytes(1_000_000, 64, 128, 0) > 0
 
 
 def test_no_cpu_fallback(pkg):

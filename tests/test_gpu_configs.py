@@ -202,3 +202,46 @@ def test_cfg3_bf16_train_step_at_4096_rays(oracle, pkg, dev):
         tot = sum(pp[i] for pp in parts)
         scale = sum(float(pp[i].norm()) for pp in parts)
         assert float((tot - f).norm()) < 1e-4 * scale, i
+
+
+@pytest.mark.parametrize("bs", [512, 400])
+def test_per_rank_share_of_a_strong_scaling_step(oracle, pkg, dev, bs):
+    """What one rank of an 8-GPU strong-scaling job computes (bench.py `per_rank_proxy` / `extra.strong_*`): 512 rays = 4096 / 8, and
+    the reference's own default batch of 400 rays (conf/lego.ini:7), as a slice of a cfg2 batch that does NOT start at ray 0, with the
+    global ray 0's (near, far) forwarded (quirk Q6).  Forward <= 1e-4 against the oracle; one train step: loss to 1e-5, every gradient
+    inside twice the oracle's own 1e-6 sensitivity (the bar of test_train_step_end_to_end); the bf16-MLP variant of the same slice
+    against its emulation."""
+    from conftest import l2_rel
+
+    row, col, pb, K, Ct = oracle.lego_inputs(4096, seed=21)
+    lo = 3 * bs
+    sl = slice(lo, lo + bs)
+    w = oracle.make_weights(3, sharp=True)
+    m = pkg.NeRFModel(64, 128, bs)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    m.ray0_near_far = pkg.parallel.global_ray0(pb)
+    r, c, p_, ct = row[sl], col[sl], pb[sl], Ct[sl]
+    with torch.no_grad():
+        Cc, Cf = m(r, c, p_, K)
+        oc, of = oracle.render(w, r, c, p_, K, 64, 128)
+    assert max_rel(Cc, oc) < TOL and max_rel(Cf, of) < TOL
+    assert _elementwise_rel(Cf, of) < 5 * TOL
+    # train step
+    Cc, Cf = m(r, c, p_, K)
+    loss = m.ray_loss(Cc, Cf, ct.to(dev))
+    loss.backward()
+    _, _, oloss, g0 = oracle.loss_and_grads(w, r, c, p_, K, ct, 64, 128)
+    assert abs(float(loss.detach()) - float(oloss)) <= 1e-5 * float(oloss)
+    gen = torch.Generator().manual_seed(1)
+    wp = {k: v * (1.0 + 1e-6 * torch.randn(v.shape, generator=gen)) for k, v in w.items()}
+    _, _, _, g1 = oracle.loss_and_grads(wp, r, c, p_, K, ct, 64, 128)
+    for (k, g), q in zip(g0.items(), m.network.parameters()):
+        bar = max(2.0 * l2_rel(g1[k], g), 1e-3)
+        assert torch.isfinite(q.grad).all() and l2_rel(q.grad, g) < bar, (k, l2_rel(q.grad, g), bar)
+    # bf16-MLP variant of the same share against its emulation (bars of tests/test_gpu_bf16.py)
+    m.bf16_mlp = True
+    with torch.no_grad():
+        Bc, Bf = m(r, c, p_, K)
+        ec, ef = oracle.render(w, r, c, p_, K, 64, 128, mlp=oracle.mlp_bf16, check=False)
+    assert max_rel(Bc, ec) < 5e-3 and max_rel(Bf, ef) < 3e-2

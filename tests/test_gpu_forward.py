@@ -368,6 +368,19 @@ def test_merge_sort_network_on_adversarial_values(oracle, pkg, dev, Nc, Nf):
     got = bundle.cpu()
     assert torch.equal(got, sb)  # (== on values: a -0 and a +0 may trade places)
     assert bool(torch.isfinite(got).all())
+    # NaNs (diverged weights can produce them): torch.sort puts every NaN last, whatever its sign bit
+    nan_ch = [c.clone() for c in ch]
+    for c in nan_ch:
+        m = torch.rand(B, N, generator=gen) < 0.03
+        c[m] = float("nan")
+        c[torch.rand(B, N, generator=gen) < 0.01] = -torch.tensor(float("nan"))
+    t_all, r, g, b, sg = nan_ch
+    rgb = torch.stack((r, g, b), dim=2)
+    bundle, w, C_f = pkg.ops.merge_composite(d(t_all[:, :Nc]), d(t_all[:, Nc:]), d(sg[:, :Nc]), d(sg[:, Nc:]), d(rgb[:, :Nc]), d(rgb[:, Nc:]))
+    sb, _ = torch.sort(torch.cat((t_all.unsqueeze(2), rgb, sg.unsqueeze(2)), dim=2), dim=1)
+    got = bundle.cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(sb))
+    assert torch.equal(torch.nan_to_num(got, nan=0.0), torch.nan_to_num(sb, nan=0.0))
 
 
 def test_near_equal_far_is_flagged_where_the_reference_exits(oracle, pkg, dev):

@@ -52,6 +52,23 @@ def _worker(rank, world, port, q):
         full = torch.arange(n * 3, dtype=torch.float32).view(n, 3)
         got = par.gather_rows(full[lo:hi].clone(), n, rank, world)
         ok &= torch.equal(got, full)
+        # the defaults of render_rows_sharded (shards on the reference's batch grid) composed with gather_rows: the batch must be
+        # named, and a shard of the wrong length is an error instead of misplaced rows
+        batch = 100
+        blo, bhi = par.batch_shard_bounds(n, batch, rank, world)
+        ok &= (blo, bhi) == ((0, 600) if rank == 0 else (600, n))
+        got = par.gather_rows(full[blo:bhi].clone(), n, rank, world, batch=batch)
+        ok &= torch.equal(got, full)
+        try:
+            par.gather_rows(full[blo:bhi].clone(), n, rank, world)  # plain shard_bounds are [0, 502) / [502, 1003)
+            ok = False
+        except ValueError:
+            pass
+        dist.barrier()
+        # overwrite protection of the bucket: a consumed bucket accepts a new backward, a pending one does not
+        b.pending = True
+        b.allreduce_sum()
+        ok &= b.pending is False
         pb = torch.zeros(4, 17, dtype=torch.float64)
         pb[0, 15], pb[0, 16] = 2.1, 6.3
         ok &= par.global_ray0(pb) == (float(torch.tensor(2.1, dtype=torch.float32)), float(torch.tensor(6.3, dtype=torch.float32)))
