@@ -27,18 +27,22 @@ enum { RF_R = 0, RF_O = 9, RF_DCAM = 12, RF_DWRD = 15, RF_NEAR = 18, RF_FAR = 19
 // A segment holds W[nft*32 features][KB*8 inputs] as float4[nft][KB][64 lanes]:
 //   lane l, component s  =  W[ft*32 + (l&31)][kb*8 + 4*(l>>5) + s]     (0 beyond the real K)
 struct Seg { int off4; int nft; int kb; };  // off4 in float4 units
-// forward segments
+// forward segments.  point_info has no activation (nerf.py:117), so point_info and the feature columns of dir_info are ONE linear
+// map of h7: pre_dir = W_dir[:, :24] gamma_d + (W_dir[:, 24:] W_pi) h7 + (W_dir[:, 24:] b_pi + b_dir).  The register kernels run the
+// folded 128 x 256 matrix SEG_FOLD (built per call by k_fold_weights, fp32 fma chains) instead of SEG_PI + SEG_DIR: 1,032 of the
+// 9,288 MFMAs of a tile less, forward and backward; the LDS-tile kernels (A/B reference) keep the two-step form.
+// (the order L5, L6, L7, PI and T_DIR, T_PI, T_L7 ... is relied upon by the tile kernels: consecutive segments of equal size)
 constexpr int SEG_L0 = 0, SEG_L1 = 1, SEG_L2 = 2, SEG_L3 = 3, SEG_L4A = 4, SEG_L4B = 5, SEG_L5 = 6, SEG_L6 = 7,
-              SEG_L7 = 8, SEG_PI = 9, SEG_DIR = 10, NSEG_FWD = 11;
+              SEG_L7 = 8, SEG_PI = 9, SEG_DIR = 10, SEG_FOLD = 11, NSEG_FWD = 12;
 // transposed segments for the backward dX chain (features <-> inputs swapped)
-constexpr int SEG_T_DIR = 11, SEG_T_PI = 12, SEG_T_L7 = 13, SEG_T_L6 = 14, SEG_T_L5 = 15, SEG_T_L4A = 16, SEG_T_L4B = 17,
-              SEG_T_L3 = 18, SEG_T_L2 = 19, SEG_T_L1 = 20, SEG_T_L0 = 21, NSEG = 22;
+constexpr int SEG_T_DIR = 12, SEG_T_PI = 13, SEG_T_L7 = 14, SEG_T_L6 = 15, SEG_T_L5 = 16, SEG_T_L4A = 17, SEG_T_L4B = 18,
+              SEG_T_L3 = 19, SEG_T_L2 = 20, SEG_T_L1 = 21, SEG_T_L0 = 22, SEG_T_FOLD = 23, NSEG = 24;
 
 __host__ __device__ constexpr int seg_nft(int s) {
-  return (s == SEG_DIR) ? 4 : (s <= SEG_PI) ? 8 : (s == SEG_T_L4B || s == SEG_T_L0) ? 2 : 8;
+  return (s == SEG_DIR || s == SEG_FOLD) ? 4 : (s == SEG_T_L4B || s == SEG_T_L0) ? 2 : 8;
 }
 __host__ __device__ constexpr int seg_kb(int s) {
-  return (s == SEG_L0 || s == SEG_L4B) ? 8 : (s <= SEG_DIR) ? 32 : (s == SEG_T_DIR) ? 16 : 32;
+  return (s == SEG_L0 || s == SEG_L4B) ? 8 : (s == SEG_T_DIR || s == SEG_T_FOLD) ? 16 : 32;
 }
 __host__ __device__ constexpr int seg_off4(int s) {
   int o = 0;
@@ -58,14 +62,17 @@ __device__ __constant__ const uint32_t kFreqDirBits[4] = {0x40490fdbu, 0x40fd527
 enum { W_L0 = 0, B_L0 = 1, W_SIGMA = 16, B_SIGMA = 17, W_PI = 18, B_PI = 19, W_DIR = 20, B_DIR = 21, W_COLOR = 22, B_COLOR = 23 };
 
 struct Weights24 { const float* p[24]; };
+// the folded matrix of point_info and dir_info's feature columns, plain row-major in the workspace: W_fold[128][256], then b_fold[128]
+// (= W_dir[:, 24:] b_pi; k_rays adds it to every ray's dir_info start vector)
+constexpr int FOLD_FLOATS = HALF * WIDTH + HALF;
 struct Grads24 { float* p[24]; };
 
 // ---- workspace carve-up (host side, api.cpp) ----
 struct WsLayout {
-  size_t status, dbg, packed, packed_bf, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
+  size_t status, dbg, packed, packed_bf, fold, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
   // training-only
   size_t packed_bf_bwd, bsave, bmask, bG, bslabs;  // bf16-MLP training (fragment layout, bf16_common.h)
-  size_t perm, w_m, bundle, save, masks, spre, G, dz, dspre, drgb_c, dsig_c, drgb_f, dsig_f, dt_f, slabs, sbuf, gdbuf;
+  size_t perm, w_m, bundle, save, masks, spre, G, dz, dspre, drgb_c, dsig_c, drgb_f, dsig_f, dt_f, slabs, sbuf, gdbuf, mbuf;
   size_t total;
 };
 

@@ -41,7 +41,7 @@ struct FieldArgs {
   float* pts_dbg;          // [M][3] or null
   float* gp_dbg;           // [M][60] or null
   // ---- training only (SAVE): rows of the coarse pass come first, then the fine pass, in every buffer
-  float* save;             // [NSAVE][Mtot][256]: h0..h7, feat, c (128 used), gamma_p (64 used)
+  float* save;             // [NSAVE][Mtot][256]: h0..h7, c (128 used), gamma_p (64 used)
   uint16_t* masks;         // [8][tiles_tot][4][256]: ReLU masks of h0..h7 in accumulator layout
   float* spre;             // [Mtot] sigma pre-activation
   int row0;                // first row of this pass in the combined buffers
@@ -54,9 +54,11 @@ struct FieldArgs {
   unsigned long long* stamps;  // diagnostic build (-DNERF_STAMPS) only: [8] cycle sums per phase
 };
 
-constexpr int S_H0 = 0, S_FEAT = 8, S_C = 9, S_GP = 10, NSAVE = 11;
-// gradient buffers written by the backward chain: dpre of layers 0..7, of point_info (= dfeat), of dir_info
-constexpr int G_L0 = 0, G_PI = 8, G_D = 9, NGRAD = 10;
+// saved by the forward: h0..h7, c, gamma_p (feat = point_info's output is not saved: with point_info folded into dir_info no weight
+// gradient needs it, see common.h SEG_FOLD)
+constexpr int S_H0 = 0, S_C = 8, S_GP = 9, NSAVE = 10;
+// gradient buffers written by the backward chain: dpre of layers 0..7 and of dir_info
+constexpr int G_L0 = 0, G_D = 8, NGRAD = 9;
 
 struct RaysArgs {
   const int64_t* row;
@@ -68,6 +70,7 @@ struct RaysArgs {
   float* dvec;       // [B][128] or null (needs w_dir / b_dir)
   const float* w_dir;  // [128][280]
   const float* b_dir;  // [128]
+  const float* b_fold; // [128] W_dir[:, 24:] b_pi (k_fold_weights), added to dvec; or null
   float* t_c;        // [B][Nc] or null
   float* d_cam;      // [B][3] or null
   float* d_wrd;      // [B][3] or null
@@ -101,7 +104,7 @@ struct MergeArgs {
   float* C_fine;   // [B][3]
 };
 
-hipError_t launch_pack_weights(const Weights24& w, float4* out, int nseg, hipStream_t st);
+hipError_t launch_pack_weights(const Weights24& w, float* fold, float4* out, int nseg, hipStream_t st);  // fold: FOLD_FLOATS scratch (written first)
 hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st);

@@ -233,11 +233,15 @@ def test_per_rank_share_of_a_strong_scaling_step(oracle, pkg, dev, bs):
     loss.backward()
     _, _, oloss, g0 = oracle.loss_and_grads(w, r, c, p_, K, ct, 64, 128)
     assert abs(float(loss.detach()) - float(oloss)) <= 1e-5 * float(oloss)
-    gen = torch.Generator().manual_seed(1)
-    wp = {k: v * (1.0 + 1e-6 * torch.randn(v.shape, generator=gen)) for k, v in w.items()}
-    _, _, _, g1 = oracle.loss_and_grads(wp, r, c, p_, K, ct, 64, 128)
+    band = {k: 0.0 for k in g0}
+    for sd in (1, 2):  # the band of test_train_step_end_to_end: maximum over two seeded perturbations
+        gen = torch.Generator().manual_seed(sd)
+        wp = {k: v * (1.0 + 1e-6 * torch.randn(v.shape, generator=gen)) for k, v in w.items()}
+        _, _, _, g1 = oracle.loss_and_grads(wp, r, c, p_, K, ct, 64, 128)
+        for k in g0:
+            band[k] = max(band[k], l2_rel(g1[k], g0[k]))
     for (k, g), q in zip(g0.items(), m.network.parameters()):
-        bar = max(2.0 * l2_rel(g1[k], g), 1e-3)
+        bar = max(2.0 * band[k], 1e-3)
         assert torch.isfinite(q.grad).all() and l2_rel(q.grad, g) < bar, (k, l2_rel(q.grad, g), bar)
     # bf16-MLP variant of the same share against its emulation (bars of tests/test_gpu_bf16.py)
     m.bf16_mlp = True
