@@ -55,10 +55,10 @@ int check_sizes(int B, int Nc, int Nf) {
 size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 
 
-// The twelve weight-gradient products of the fp32 train step (dw_f32.hip) -- eleven MFMA-bound ones, one of them carrying the sigma
+// The eleven weight-gradient products of the fp32 train step (dw_f32.hip) -- ten MFMA-bound ones, one of them carrying the sigma
 // head, + the thin colour head -- in launch order, with their slab offsets; pointers are filled in by nerf_hip_backward (null
 // here: only sizes matter for the layout).
-long long build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw) {
+long long build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw, float* mbuf) {
   memset(&b, 0, sizeof(b));
   auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db) -> DwItem& {
     DwItem& it = b.item[b.n++];
@@ -73,9 +73,10 @@ long long build_dw_batch(DwBatch& b, const float* G, const float* save, const fl
   add(Gt(4), 256, St(S_GP), 64, POINT_DIM, D(8), WIDTH + POINT_DIM, WIDTH, nullptr);            // layer 4, skip columns
   // layer 0 (X = gamma_p): HBM-bound like the one above; NOT first -- right behind the chain kernel it ran 20 % longer
   add(Gt(0), 256, St(S_GP), 64, POINT_DIM, D(0), POINT_DIM, 0, D(1));
-  DwItem& pi = add(Gt(G_PI), 256, St(7), 256, 256, D(W_PI), WIDTH, 0, D(B_PI));                  // point_info ...
-  pi.has_sig = 1; pi.sig = dz4 ? dz4 + 3 : nullptr; pi.dW2 = D(W_SIGMA);                         // ... + the sigma head (same X = h7)
-  add(Gt(G_D), 128, St(S_FEAT), 256, 256, D(W_DIR), WIDTH + DIR_DIM, DIR_DIM, D(B_DIR));         // dir_info, feature columns
+  // point_info folded into dir_info (common.h SEG_FOLD): M = dpre_dir^T h7 (128 x 256) instead of the 256 x 256 point_info product and
+  // dir_info's feature columns; k_fold_grads turns M into both tensors' gradients.  The sigma head rides on it (same X = h7).
+  DwItem& mi = add(Gt(G_D), 128, St(7), 256, 256, mbuf, WIDTH, 0, D(B_DIR));
+  mi.has_sig = 1; mi.sig = dz4 ? dz4 + 3 : nullptr; mi.dW2 = D(W_SIGMA);
   DwItem& th = add(dz4, 32, St(S_C), 128, 128, D(W_COLOR), HALF, 0, D(B_COLOR));                 // colour head (X = c) + the bias gradients of both heads
   th.thin = 1; th.db2 = D(B_SIGMA);
   // Every product gets ALL DW_WGS workgroups in a launch of its own.  (One launch for all products, the CUs dealt out in
@@ -91,7 +92,7 @@ long long build_dw_batch(DwBatch& b, const float* G, const float* save, const fl
 
 size_t dw_batch_slab_floats() {
   DwBatch b;
-  return (size_t)build_dw_batch(b, nullptr, nullptr, nullptr, 0, nullptr);
+  return (size_t)build_dw_batch(b, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 WsLayout layout(int B, int Nc, int Nf, int flags) {
@@ -105,6 +106,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
   L.dbg = take(DBG_WORDS * 8);  // diagnostic builds (-DNERF_STAMPS) write cycle stamps here; untouched otherwise
   L.packed = take((size_t)PACKED_ALL_F4 * 16);
   if (flags & NERF_HIP_BF16_MLP) L.packed_bf = take(BF_IMAGE_BYTES);
+  L.fold = take(FOLD_FLOATS * 4);
   L.rayf = take(b * RAYF * 4);
   L.dvec = take(b * HALF * 4);
   L.t_c = take(b * Nc * 4);
@@ -137,6 +139,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
       L.slabs = take(dw_batch_slab_floats() * 4);  // every product of the step keeps its own slabs: ONE reduce launch at the end
       L.sbuf = take(2 * b * HALF * 4);
       L.gdbuf = take(b * DIR_DIM * 4);
+      L.mbuf = take((size_t)HALF * WIDTH * 4);
     }
     L.drgb_c = take(b * Nc * 12);
     L.dsig_c = take(b * Nc * 4);
@@ -270,7 +273,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     ProfScope ps(NERF_HIP_K_PACK, st, &pc);
     if (bf16 && bf16x) HIP_TRY(launch_pack_weights_bf16x(w, at<unsigned char>(ws, L.packed_bf), st));
     else if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
-    else HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
+    else HIP_TRY(launch_pack_weights(w, at<float>(ws, L.fold), at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
   }
 
   RaysArgs ra;
@@ -281,6 +284,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ra.rayf = at<float>(ws, L.rayf);
   ra.dvec = at<float>(ws, L.dvec);
   ra.w_dir = w.p[W_DIR]; ra.b_dir = w.p[B_DIR];
+  ra.b_fold = bf16 ? nullptr : at<float>(ws, L.fold);  // (the bf16 kernels do not read dvec)
   ra.t_c = at<float>(ws, L.t_c);
   ra.status = at<unsigned>(ws, L.status);  // zeroed by the kernel (the later kernels OR their flags into it)
   { ProfScope ps(NERF_HIP_K_RAYS, st, &pc); HIP_TRY(launch_rays(ra, st)); }
@@ -500,7 +504,7 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   } else {
     ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
     DwBatch batch;
-    build_dw_batch(batch, G, save, at<float>(ws, L.dz), MS, dw);
+    build_dw_batch(batch, G, save, at<float>(ws, L.dz), MS, dw, at<float>(ws, L.mbuf));
     float* slabs = at<float>(ws, L.slabs);
     batch.slabs = slabs;
 #ifdef NERF_STAMPS
@@ -517,6 +521,10 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     }
     HIP_TRY(launch_dw(batch, Mtot, slabs, st));
     HIP_TRY(launch_dw_reduce(batch, st));
+    FoldGradArgs fg;
+    fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
+    fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
+    HIP_TRY(launch_fold_grads(fg, st));
     // direction-encoding columns of dir_info (per-ray sums)
     SmallGradArgs sg;
     memset(&sg, 0, sizeof(sg));
@@ -537,7 +545,7 @@ int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_
       {"status", L.status}, {"dbg", L.dbg}, {"packed", L.packed}, {"packed_bf", L.packed_bf}, {"bsave", L.bsave}, {"bmask", L.bmask}, {"bG", L.bG}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
       {"rgb_c", L.rgb_c}, {"w_c", L.w_c}, {"t_f", L.t_f}, {"sig_f", L.sig_f}, {"rgb_f", L.rgb_f}, {"perm", L.perm},
       {"w_m", L.w_m}, {"bundle", L.bundle}, {"save", L.save}, {"masks", L.masks}, {"spre", L.spre}, {"G", L.G}, {"dz", L.dz},
-      {"dspre", L.dspre}, {"drgb_c", L.drgb_c}, {"dsig_c", L.dsig_c}, {"drgb_f", L.drgb_f}, {"dsig_f", L.dsig_f},
+      {"dspre", L.dspre}, {"mbuf", L.mbuf}, {"fold", L.fold}, {"drgb_c", L.drgb_c}, {"dsig_c", L.dsig_c}, {"drgb_f", L.drgb_f}, {"dsig_f", L.dsig_f},
       {"dt_f", L.dt_f}, {"slabs", L.slabs}, {"masks", L.masks}, {"sbuf", L.sbuf}, {"gdbuf", L.gdbuf}};
   for (auto& e : tab)
     if (strcmp(e.n, name) == 0) {
@@ -589,7 +597,7 @@ int nerf_hip_field(const float* const* weights24, const int64_t* row, const int6
   if (int rc = check_device()) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Weights24 w = as_w24(weights24);
-  HIP_TRY(launch_pack_weights(w, at<float4>(ws, L.packed), NSEG_FWD, st));
+  HIP_TRY(launch_pack_weights(w, at<float>(ws, L.fold), at<float4>(ws, L.packed), NSEG_FWD, st));
   RaysArgs ra;
   memset(&ra, 0, sizeof(ra));
   ra.row = row; ra.col = col; ra.pb = poses_bound;
@@ -597,7 +605,7 @@ int nerf_hip_field(const float* const* weights24, const int64_t* row, const int6
   ra.B = B; ra.Nc = Nl;
   ra.rayf = at<float>(ws, L.rayf);
   ra.dvec = at<float>(ws, L.dvec);
-  ra.w_dir = w.p[W_DIR]; ra.b_dir = w.p[B_DIR];
+  ra.w_dir = w.p[W_DIR]; ra.b_dir = w.p[B_DIR]; ra.b_fold = at<float>(ws, L.fold);
   HIP_TRY(launch_rays(ra, st));
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));

@@ -29,7 +29,7 @@ enum { RF_R = 0, RF_O = 9, RF_DCAM = 12, RF_DWRD = 15, RF_NEAR = 18, RF_FAR = 19
 struct Seg { int off4; int nft; int kb; };  // off4 in float4 units
 // forward segments.  point_info has no activation (nerf.py:117), so point_info and the feature columns of dir_info are ONE linear
 // map of h7: pre_dir = W_dir[:, :24] gamma_d + (W_dir[:, 24:] W_pi) h7 + (W_dir[:, 24:] b_pi + b_dir).  The register kernels run the
-// folded 128 x 256 matrix SEG_FOLD (built per call by k_fold_weights, fp32 fma chains) instead of SEG_PI + SEG_DIR: 1,032 of the
+// folded 128 x 256 matrix SEG_FOLD (built per call by k_pack_weights, fp32 fma chains) instead of SEG_PI + SEG_DIR: 1,032 of the
 // 9,288 MFMAs of a tile less, forward and backward; the LDS-tile kernels (A/B reference) keep the two-step form.
 // (the order L5, L6, L7, PI and T_DIR, T_PI, T_L7 ... is relied upon by the tile kernels: consecutive segments of equal size)
 constexpr int SEG_L0 = 0, SEG_L1 = 1, SEG_L2 = 2, SEG_L3 = 3, SEG_L4A = 4, SEG_L4B = 5, SEG_L5 = 6, SEG_L6 = 7,
@@ -62,9 +62,8 @@ __device__ __constant__ const uint32_t kFreqDirBits[4] = {0x40490fdbu, 0x40fd527
 enum { W_L0 = 0, B_L0 = 1, W_SIGMA = 16, B_SIGMA = 17, W_PI = 18, B_PI = 19, W_DIR = 20, B_DIR = 21, W_COLOR = 22, B_COLOR = 23 };
 
 struct Weights24 { const float* p[24]; };
-// the folded matrix of point_info and dir_info's feature columns, plain row-major in the workspace: W_fold[128][256], then b_fold[128]
-// (= W_dir[:, 24:] b_pi; k_rays adds it to every ray's dir_info start vector)
-constexpr int FOLD_FLOATS = HALF * WIDTH + HALF;
+// b_fold[128] = W_dir[:, 24:] b_pi in the workspace (k_pack_weights; k_rays adds it to every ray's dir_info start vector)
+constexpr int FOLD_FLOATS = HALF;
 struct Grads24 { float* p[24]; };
 
 // ---- workspace carve-up (host side, api.cpp) ----

@@ -12,6 +12,8 @@
 //                 output tile per wave, X = c; the column sums of A are the bias gradients of both heads.  HBM-bound.
 //  k_dw_reduce    ONE launch per step: sums the slabs of all products in a fixed order (deterministic, no float atomics)
 //                 and scatters into the nn.Linear-layout gradients.
+//  k_fold_grads   point_info is folded into dir_info (common.h SEG_FOLD): ONE 128 x 256 product (dpre_dir^T h7) replaces the
+//                 256 x 256 point_info product and dir_info's feature columns; this kernel turns it into the two tensors' gradients.
 //
 // Autograd spans replaced: the weight / bias gradients of Network.forward (nerf.py:101-124) as produced by
 // loss.backward() at nerf.py:473.
@@ -151,6 +153,14 @@ struct DwFrag {
 
 // what a wave does besides its block (one extra duty per wave at most, so that the four waves of a workgroup stay level):
 constexpr int DW_PLAIN = 0, DW_BIAS = 1, DW_SIG = 2, DW_BIAS_LO = 3, DW_BIAS_HI = 4, DW_RAY_LO = 5, DW_RAY_HI = 6;
+// the 128 x 256 product of dpre_dir with h7 (point_info folded into dir_info, common.h SEG_FOLD) has only two waves per operand block
+// and three duties -- the sigma head (X = h7), dir_info's bias gradient and the per-ray sums: every wave carries the sigma head for ITS
+// 128 columns of h7 and half of the column sums (6 VALU + one 4-byte load per 16 MFMAs: 2.6 % of ONE product)
+constexpr int DW_SIG_BIAS_LO = 7, DW_SIG_BIAS_HI = 8, DW_SIG_RAY_LO = 9, DW_SIG_RAY_HI = 10;
+__host__ __device__ constexpr bool duty_sig(int d) { return d == DW_SIG || d >= DW_SIG_BIAS_LO; }
+__host__ __device__ constexpr bool duty_ray(int d) { return d == DW_RAY_LO || d == DW_RAY_HI || d == DW_SIG_RAY_LO || d == DW_SIG_RAY_HI; }
+__host__ __device__ constexpr bool duty_lo(int d) { return d == DW_BIAS_LO || d == DW_RAY_LO || d == DW_SIG_BIAS_LO || d == DW_SIG_RAY_LO; }
+__host__ __device__ constexpr bool duty_hi(int d) { return d == DW_BIAS_HI || d == DW_RAY_HI || d == DW_SIG_BIAS_HI || d == DW_SIG_RAY_HI; }
 // DW_BIAS  column sums of its 128 columns of G = bias gradient (4 adds per k-step)
 // DW_BIAS_LO / _HI  the same sums shared by the two waves that read the same G block: columns 4q, 4q+1 / 4q+2, 4q+3 (2 adds per k-step)
 // DW_RAY_LO / _HI   as DW_BIAS_LO / _HI, and the sums of every ray's rows are written out on the way (dir_info: the gamma_d columns need them)
@@ -163,13 +173,15 @@ struct RayDuty {
 
 // rows [r_begin, r_end) (wave-uniform, a multiple of 2 DW4_DEPTH rows long).  gbase / xbase / sbase: wave-uniform operand
 // pointers at row 0; goff / xoff / soff: this lane's byte offset inside a row pair (row h, column group q).
+// bsum: the duty's sums (column sums of G; DW_SIG alone: the sigma head's); ssum: the sigma head's sums of the combined duties
 template <int NCB, int DUTY>
 __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const float* __restrict__ xbase, const float* __restrict__ sbase, const unsigned goff,
                                           const unsigned xoff, const unsigned soff, const int r_begin, const int r_end, f32x16 (&acc)[4][NCB], float (&bsum)[4],
-                                          const RayDuty rd = RayDuty{nullptr, 0, 0, 0, 0}, const int lane = 0) {
+                                          const RayDuty rd = RayDuty{nullptr, 0, 0, 0, 0}, const int lane = 0, float* ssum = nullptr) {
   typedef typename DwVecB<NCB>::type VB;
   constexpr int D = DW4_DEPTH;
-  constexpr bool RAY = DUTY == DW_RAY_LO || DUTY == DW_RAY_HI;
+  constexpr bool RAY = duty_ray(DUTY);
+  constexpr bool SIG2 = DUTY >= DW_SIG_BIAS_LO;  // sigma head next to column sums: its sums live in ssum
   DwFrag<NCB> s[D];
   float rs[2] = {0.f, 0.f};  // RAY: this lane's sums over the rows of the current ray (its two columns, its row parity)
   const int r_last = r_end - 2;
@@ -181,7 +193,7 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
     asm volatile("" : "+v"(go), "+v"(xo));  // opaque here: otherwise base + lane offset is hoisted as a 64-bit vector and every load pays a 64-bit vector add
     S.a = *reinterpret_cast<const float4*>(ga + go);
     S.b = *reinterpret_cast<const VB*>(xa + xo);
-    if (DUTY == DW_SIG) S.sg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase + (size_t)r * 4) + soff);
+    if (duty_sig(DUTY)) S.sg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase + (size_t)r * 4) + soff);
   };
   auto mul = [&](const DwFrag<NCB>& S) {
 #pragma unroll
@@ -208,13 +220,25 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[2]) : "v"(S.a.z));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[3]) : "v"(S.a.w));
     }
-    if (DUTY == DW_RAY_LO) {
+    if (DUTY == DW_RAY_LO || DUTY == DW_SIG_RAY_LO) {
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(rs[0]) : "v"(S.a.x));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(rs[1]) : "v"(S.a.y));
     }
-    if (DUTY == DW_RAY_HI) {
+    if (DUTY == DW_RAY_HI || DUTY == DW_SIG_RAY_HI) {
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(rs[0]) : "v"(S.a.z));
       asm volatile("v_add_f32 %0, %0, %1" : "+v"(rs[1]) : "v"(S.a.w));
+    }
+    if (DUTY == DW_SIG_BIAS_LO) {
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[0]) : "v"(S.a.x));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[1]) : "v"(S.a.y));
+    }
+    if (DUTY == DW_SIG_BIAS_HI) {
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[2]) : "v"(S.a.z));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[3]) : "v"(S.a.w));
+    }
+    if (SIG2) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(ssum[cb]) : "v"(S.sg), "v"(comp(S.b, cb)));
     }
   };
   // RAY: which ray the range starts in and how many of its rows are left (ranges start and end on ray boundaries: dw_ray_duty_ok)
@@ -236,7 +260,7 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
     if (RAY) {  // (wave-uniform) a ray's rows end with this round: its sums go out, the column sums take them over
       left -= 2 * D;
       if (left == 0) {
-        constexpr int c0 = DUTY == DW_RAY_LO ? 0 : 2;
+        constexpr int c0 = duty_lo(DUTY) ? 0 : 2;
         bsum[c0] += rs[0];
         bsum[c0 + 1] += rs[1];
         const float t0 = rs[0] + __shfl_xor(rs[0], 32), t1 = rs[1] + __shfl_xor(rs[1], 32);
@@ -258,7 +282,7 @@ __device__ __forceinline__ void dw_stream(const float* __restrict__ gbase, const
 template <int NCB>
 __device__ __forceinline__ void dw_stream_tail(const float* __restrict__ gbase, const float* __restrict__ xbase, const float* __restrict__ sbase, const unsigned goff,
                                                const unsigned xoff, const unsigned soff, const int h, const int r_begin, const int r_end, const int duty,
-                                               f32x16 (&acc)[4][NCB], float (&bsum)[4]) {
+                                               f32x16 (&acc)[4][NCB], float (&bsum)[4], float* ssum = nullptr) {
   typedef typename DwVecB<NCB>::type VB;
   for (int r0 = r_begin; r0 < r_end; r0 += 2) {
     const bool live = r0 + h < r_end;
@@ -266,18 +290,22 @@ __device__ __forceinline__ void dw_stream_tail(const float* __restrict__ gbase, 
     float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gbase + (size_t)r * WIDTH) + goff);
     const VB b = *reinterpret_cast<const VB*>(reinterpret_cast<const char*>(xbase + (size_t)r * WIDTH) + xoff);
     float sg = 0.f;
-    if (duty == DW_SIG && live) sg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase + (size_t)r * 4) + soff);
+    if (duty_sig(duty) && live) sg = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase + (size_t)r * 4) + soff);
     if (!live) a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a, ca), comp(b, cb), acc[ca][cb], 0, 0, 0);
     if (duty == DW_BIAS) { bsum[0] += a.x; bsum[1] += a.y; bsum[2] += a.z; bsum[3] += a.w; }
-    if (duty == DW_BIAS_LO || duty == DW_RAY_LO) { bsum[0] += a.x; bsum[1] += a.y; }  // (the ray duties never get here: dw_ray_duty_ok)
-    if (duty == DW_BIAS_HI || duty == DW_RAY_HI) { bsum[2] += a.z; bsum[3] += a.w; }
+    if (duty_lo(duty)) { bsum[0] += a.x; bsum[1] += a.y; }  // (the ray duties never get here: dw_ray_duty_ok)
+    if (duty_hi(duty)) { bsum[2] += a.z; bsum[3] += a.w; }
     if (duty == DW_SIG) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) bsum[cb] = __builtin_fmaf(sg, comp(b, cb), bsum[cb]);
+    }
+    if (duty >= DW_SIG_BIAS_LO) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) ssum[cb] = __builtin_fmaf(sg, comp(b, cb), ssum[cb]);
     }
   }
 }
@@ -306,7 +334,11 @@ __host__ __device__ inline size_t dwi_sums_off(const DwItem& p, int lw) { return
 __host__ __device__ inline int dwi_duty(const DwItem& p, int bi, int bj) {
   const int in_blocks = dwi_in_blocks(p);
   if (p.thin) return bj == 0 ? 1 : 0;
-  if (p.has_sig) {  // the 256 x 256 point_info product: sigma head on the diagonal waves, column sums on the other two
+  if (p.has_sig && p.nout == 128) {  // dpre_dir^T h7: sigma head on every wave (its own 128 columns of h7) + half of the column sums
+    if (p.raysum) return bj == 0 ? 9 : 10;           // DW_SIG_RAY_LO / _HI
+    return bj == 0 ? 7 : 8;                          // DW_SIG_BIAS_LO / _HI
+  }
+  if (p.has_sig) {  // a 256 x 256 product carrying the sigma head: on the diagonal waves, column sums on the other two
     if (bj == bi) return 2;                          // DW_SIG
     return p.db ? 1 : 0;                             // DW_BIAS
   }
@@ -316,6 +348,7 @@ __host__ __device__ inline int dwi_duty(const DwItem& p, int bi, int bj) {
   return bj == 0 ? 1 : 0;                            // DW_BIAS (one wave per G block)
 }
 __host__ __device__ inline bool dwi_sums_columns(int duty) { return duty == 1 || duty >= 3; }
+__host__ __device__ inline bool dwi_sums_sigma(int duty) { return duty == 2 || duty >= 7; }
 
 // The colour head as one thin product: A = the [rows][4] buffer (dz_r, dz_g, dz_b, dsigma_pre), one 32-row output tile per wave,
 // X = c in two 64-column blocks x four row sub-ranges; rows 0..2 of the result are dW_color, the column sums of A (waves of
@@ -366,7 +399,10 @@ __global__ __launch_bounds__(512, 2) void k_dw_thin(const DwItem p, const long l
 }
 
 // One workgroup's share of one big product, 4 waves: wave = (block, row sub-range); block = 128 columns of G x 32 NCB columns of X.
-template <int NCB>
+// MIXED: the 128 x 256 product that carries the sigma head AND column sums on every wave (DW_SIG_*): a kernel of its own, so that the
+// loops of the other products keep the schedule they were tuned with (this compiler schedules the stage loads of a loop differently
+// when other loops share its kernel).
+template <int NCB, bool MIXED = false>
 __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
   const int lane = threadIdx.x & 63, lw = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -395,6 +431,7 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f};  // MIXED: the sigma head's sums (bsum: column sums)
 
   const int bi = blk / in_blocks, bj = blk % in_blocks;
   const float* gbase = p.G + bi * 128;
@@ -402,6 +439,28 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
   const float* sbase = p.sig;
   const unsigned goff = (unsigned)(h * WIDTH + 4 * q) * 4u, xoff = (unsigned)(h * WIDTH + NCB * q) * 4u, soff = (unsigned)h * 16u;
   const int duty = dwi_duty(p, bi, bj);  // wave-uniform
+  if constexpr (MIXED) {
+    if (r_begin < r_end) {
+      if (r_nom <= Mrows) {
+        const RayDuty rd{p.raysum, p.ray_nc, p.ray_nf, p.rows_c, p.rows_c / (p.ray_nc > 0 ? p.ray_nc : 1)};
+        if (duty == DW_SIG_RAY_LO) {
+          asm volatile("; sigma head + per-ray sums, low half" ::: "memory");
+          dw_stream<NCB, MIXED ? DW_SIG_RAY_LO : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum, rd, lane, ssum);
+        } else if (duty == DW_SIG_RAY_HI) {
+          asm volatile("; sigma head + per-ray sums, high half" ::: "memory");
+          dw_stream<NCB, MIXED ? DW_SIG_RAY_HI : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum, rd, lane, ssum);
+        } else if (duty == DW_SIG_BIAS_LO) {
+          asm volatile("; sigma head + column sums, low half" ::: "memory");
+          dw_stream<NCB, MIXED ? DW_SIG_BIAS_LO : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum, rd, lane, ssum);
+        } else {
+          asm volatile("; sigma head + column sums, high half" ::: "memory");
+          dw_stream<NCB, MIXED ? DW_SIG_BIAS_HI : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum, rd, lane, ssum);
+        }
+      } else {
+        dw_stream_tail<NCB>(gbase, xbase, sbase, goff, xoff, soff, h, r_begin, r_end, duty, acc, bsum, ssum);
+      }
+    }
+  } else
   if (r_begin < r_end) {
     if (r_nom <= Mrows) {
       // (the empty asm statements differ on purpose: identical starts of the branches get hoisted into this block, and the
@@ -446,6 +505,10 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
   // the duty's sums: 4 columns per lane (bias: columns 4q.. of the G block; sigma head: columns NCB q.. of the X block), rows h, h + 2, ...
 #pragma unroll
   for (int c = 0; c < 4; ++c) bsum[c] += __shfl_xor(bsum[c], 32);
+  if (MIXED) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ssum[c] += __shfl_xor(ssum[c], 32);
+  }
   if (h == 0) {
     float* bs = sl + dwi_sums_off(p, lw) + (size_t)wv * 128;
     float* sg = bs + 4 * 128;
@@ -454,7 +517,7 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
     for (int c = 0; c < 4; ++c) bs[4 * q + c] = is_sig ? 0.f : bsum[c];
     if (p.has_sig) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sg[4 * q + c] = is_sig ? bsum[c] : 0.f;
+      for (int c = 0; c < 4; ++c) sg[4 * q + c] = MIXED ? ssum[c] : (is_sig ? bsum[c] : 0.f);
     }
   }
 #ifdef NERF_STAMPS
@@ -560,7 +623,7 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
     const float* sg = base + dwi_sums_off(p, 0) + (size_t)waves * 128;
     for (int w = 0; w < waves; ++w) {
       const int blk = w % nblocks;
-      if (blk % in_blocks != bj || dwi_duty(p, blk / in_blocks, bj) != 2) continue;
+      if (blk % in_blocks != bj || !dwi_sums_sigma(dwi_duty(p, blk / in_blocks, bj))) continue;
       const float* q = sg + (size_t)w * 128 + oi;
       for (int k = kp; k < p.nwg; k += 64) s += q[(size_t)k * sums_per_wg];
     }
@@ -580,7 +643,7 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const DwBatch b) {
 // range is ragged (then the pipelined loop runs everywhere): ranges are multiples of both sample counts, the coarse pass's rows
 // are a multiple of the fine pass's samples per ray, and the rows fill whole ranges.
 bool dw_ray_duty_ok(const DwItem& p, long long Mtot, int B, int Nc, int Nf) {
-  if (p.thin || dwi_ncb(p) != 4 || dwi_in_blocks(p) != 2 || !p.db || p.has_sig) return false;
+  if (p.thin || dwi_ncb(p) != 4 || dwi_in_blocks(p) != 2 || !p.db || p.nout != 128) return false;
   if (Nc % (2 * DW4_DEPTH) || Nf % (2 * DW4_DEPTH) || Mtot != (long long)B * (Nc + Nf)) return false;
   const int msubs = dwi_msubs(p), gran = 2 * DW4_DEPTH * msubs, Mrows = (int)Mtot;
   const int per_wg = ((Mrows + p.nwg - 1) / p.nwg + gran - 1) / gran * gran, per_wave = per_wg / msubs;
@@ -589,10 +652,58 @@ bool dw_ray_duty_ok(const DwItem& p, long long Mtot, int B, int Nc, int Nf) {
 
 size_t dw_item_slab_floats(const DwItem& p) { return (size_t)p.nwg * dwi_wg_floats(p); }
 
+// point_info folded into dir_info (common.h SEG_FOLD): with M = sum_m dpre_dir[m] (x) h7[m] (128 x 256, the product above) and
+// db_dir = sum_m dpre_dir[m], the gradients of the two ORIGINAL parameter tensors follow exactly (feat = W_pi h7 + b_pi):
+//   dW_pi            = W_dir[:, 24:]^T M                  (256 x 256)      db_pi = W_dir[:, 24:]^T db_dir
+//   dW_dir[:, 24:]   = M W_pi^T + db_dir (x) b_pi         (128 x 256)
+// 16.8 M MACs per step, fp32 fma chains in a fixed order.  Blocks [0, 256): row i of dW_pi; [256, 384): row o of dW_dir; 384: db_pi.
+__global__ __launch_bounds__(256) void k_fold_grads(const FoldGradArgs a) {
+  __shared__ float mrow[WIDTH];
+  const int t = threadIdx.x, b = blockIdx.x;
+  constexpr int LD = WIDTH + DIR_DIM;
+  if (b < WIDTH) {  // dW_pi[i][k] = sum_o W_dir[o][24 + i] * M[o][k]: the W_dir element is block-uniform, M coalesced over k = t
+    const int i = b;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < HALF; o += 2) {
+      s0 = __builtin_fmaf(a.w_dir[(size_t)o * LD + DIR_DIM + i], a.M[(size_t)o * WIDTH + t], s0);
+      s1 = __builtin_fmaf(a.w_dir[(size_t)(o + 1) * LD + DIR_DIM + i], a.M[(size_t)(o + 1) * WIDTH + t], s1);
+    }
+    a.dW_pi[(size_t)i * WIDTH + t] = s0 + s1;
+  } else if (b < WIDTH + HALF) {  // dW_dir[o][24 + i] = sum_k M[o][k] * W_pi[i][k] + db_dir[o] * b_pi[i]: thread i walks ITS row of W_pi
+    const int o = b - WIDTH, i = t;
+    mrow[t] = a.M[(size_t)o * WIDTH + t];
+    __syncthreads();
+    const float4* wr = reinterpret_cast<const float4*>(a.w_pi + (size_t)i * WIDTH);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < WIDTH / 4; ++k4) {
+      const float4 q = wr[k4];
+      s0 = __builtin_fmaf(mrow[4 * k4 + 0], q.x, s0);
+      s1 = __builtin_fmaf(mrow[4 * k4 + 1], q.y, s1);
+      s2 = __builtin_fmaf(mrow[4 * k4 + 2], q.z, s2);
+      s3 = __builtin_fmaf(mrow[4 * k4 + 3], q.w, s3);
+    }
+    a.dW_dir[(size_t)o * LD + DIR_DIM + i] = __builtin_fmaf(a.db_dir[o], a.b_pi[i], (s0 + s1) + (s2 + s3));
+  } else {  // db_pi[i] = sum_o W_dir[o][24 + i] * db_dir[o]
+    const int i = t;
+    float s = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < HALF; ++o) s = __builtin_fmaf(a.w_dir[(size_t)o * LD + DIR_DIM + i], a.db_dir[o], s);
+    a.db_pi[i] = s;
+  }
+}
+
+hipError_t launch_fold_grads(const FoldGradArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_fold_grads, dim3(WIDTH + HALF + 1), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st) {
   for (int i = 0; i < b.n; ++i) {
     const DwItem& p = b.item[i];
     if (p.thin) hipLaunchKernelGGL(k_dw_thin, dim3(p.nwg), dim3(512), 0, st, p, Mtot, slabs);
+    else if (dwi_ncb(p) == 4 && p.has_sig && p.nout == 128) hipLaunchKernelGGL((k_dw4<4, true>), dim3(p.nwg), dim3(256), 0, st, p, Mtot, slabs);
     else if (dwi_ncb(p) == 4) hipLaunchKernelGGL((k_dw4<4>), dim3(p.nwg), dim3(256), 0, st, p, Mtot, slabs);
     else hipLaunchKernelGGL((k_dw4<2>), dim3(p.nwg), dim3(256), 0, st, p, Mtot, slabs);
     hipError_t e = hipGetLastError();

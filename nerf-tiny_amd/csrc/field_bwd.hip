@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256, 2) void k_field_bwd(const FieldBwdArgs a) {
   __syncthreads();
   acc_store<2, false>(act, fbase, lane, acc);
   __syncthreads();
-  save_rows(act, a.G + G_PI * MS, grow0, nrows, 64, WIDTH, tid);
 
   // ---- point_info backward + sigma head: dh7 = W_pi^T dfeat + w_sigma * dsigma_pre, masked by h7 > 0
   {

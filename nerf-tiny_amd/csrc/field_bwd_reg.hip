@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
 
   WStageB<8> st0;
 #pragma unroll
-  for (int f = 0; f < 8; ++f) st0.w[f] = (wp + seg_off4(SEG_T_DIR) + lane)[(size_t)(f * 16) * 64];
+  for (int f = 0; f < 8; ++f) st0.w[f] = (wp + seg_off4(SEG_T_FOLD) + lane)[(size_t)(f * 16) * 64];
   auto mlayer = [&](int layer) { return mrow + (size_t)layer * MKS; };
   unsigned mfirst = mask_word(mlayer(7), 0);  // first masked layer of the chain; every later word is fetched a tile ahead
 
@@ -261,20 +261,18 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
   }
   BSTAMP(0);  // prologue: colour head backward
   f32x16 A[8], B[8];
-  // ---- dir_info backward: dfeat = W_d[:, 24:]^T dpre_d  (256 <- 128); stores dpre_d
-  reg_layer_bwd<16, 8, 32, 8, true, false>(wp + seg_off4(SEG_T_DIR), wp + seg_off4(SEG_T_PI), lane, D0, A, st0, nullptr, nullptr, mfirst,
-                                           grow + G_D * MS);
-  BSTAMP(1);  // dir_info (512 MFMAs)
-  // ---- point_info backward + sigma head: dh7 = W_pi^T dfeat + w_sigma (x) dsigma_pre; stores dfeat
+  // ---- dir_info and point_info backward as ONE transposed layer (common.h SEG_FOLD), + the sigma head:
+  // dh7 = W_fold^T dpre_d + w_sigma (x) dsigma_pre  (256 <- 128); stores dpre_d
   {
     const float dsb = (h == 0) ? ds : 0.f;  // outer product as one MFMA per tile: A = w_sigma rows, B = ds on lane half 0
     const float* ws = a.w.p[W_SIGMA];
 #pragma unroll
     for (int f = 0; f < 8; ++f) B[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[f * 32 + j], dsb, zero, 0, 0, 0);
   }
-  reg_layer_bwd<32, 8, 32, 8, false, false>(wp + seg_off4(SEG_T_PI), wp + seg_off4(SEG_T_L7), lane, A, B, st0, nullptr, nullptr, mfirst,
-                                            grow + G_PI * MS);
-  BSTAMP(2);  // point_info + sigma head (1,032 MFMAs)
+  reg_layer_bwd<16, 8, 32, 8, false, false>(wp + seg_off4(SEG_T_FOLD), wp + seg_off4(SEG_T_L7), lane, D0, B, st0, nullptr, nullptr, mfirst,
+                                            grow + G_D * MS);
+  BSTAMP(1);  // dir_info + point_info folded, sigma head (520 MFMAs)
+  BSTAMP(2);
   // ---- layers 7, 6, 5: input = raw d h_l masked by h_l > 0 (= dpre_l, stored), output = raw d h_{l-1}
   const float4* const sT7 = wp + seg_off4(SEG_T_L7);
   reg_layer_bwd<32, 8, 32, 8, true, true>(sT7, sT7 + L256, lane, B, A, st0, mlayer(7), mlayer(6), mfirst, grow + 7 * MS);

@@ -70,10 +70,55 @@ constexpr SegOffTable make_seg_off_table() {
 }
 __constant__ const SegOffTable kSegOff = make_seg_off_table();
 
-__global__ __launch_bounds__(256) void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg) {
+// One element of the folded matrix W_fold[o][k] = sum_j W_dir[o][24 + j] * W_pi[j][k] (common.h SEG_FOLD): an fp32 fma chain over
+// j = 0 .. 255 in ascending order, so that the forward segment, the transposed segment and the weight-gradient kernels all see the
+// SAME fp32 matrix bit for bit.
+__device__ __forceinline__ float4 fold4_k(const float* __restrict__ wdir, const float* __restrict__ wpi, int o, int k0) {  // W_fold[o][k0 .. k0+3]
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* dr = wdir + (size_t)o * (WIDTH + DIR_DIM) + DIR_DIM;
+  const float* pc = wpi + k0;
+#pragma unroll 8
+  for (int j = 0; j < WIDTH; ++j) {
+    const float d = dr[j];
+    const float4 q = *reinterpret_cast<const float4*>(pc + (size_t)j * WIDTH);
+    acc.x = __builtin_fmaf(d, q.x, acc.x);
+    acc.y = __builtin_fmaf(d, q.y, acc.y);
+    acc.z = __builtin_fmaf(d, q.z, acc.z);
+    acc.w = __builtin_fmaf(d, q.w, acc.w);
+  }
+  return acc;
+}
+__device__ __forceinline__ float4 fold4_o(const float* __restrict__ wdir, const float* __restrict__ wpi, int o0, int k) {  // W_fold[o0 .. o0+3][k]
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* dr = wdir + (size_t)o0 * (WIDTH + DIR_DIM) + DIR_DIM;
+  const float* pc = wpi + k;
+#pragma unroll 8
+  for (int j = 0; j < WIDTH; ++j) {
+    const float q = pc[(size_t)j * WIDTH];
+    acc.x = __builtin_fmaf(dr[j], q, acc.x);
+    acc.y = __builtin_fmaf(dr[(WIDTH + DIR_DIM) + j], q, acc.y);
+    acc.z = __builtin_fmaf(dr[2 * (WIDTH + DIR_DIM) + j], q, acc.z);
+    acc.w = __builtin_fmaf(dr[3 * (WIDTH + DIR_DIM) + j], q, acc.w);
+  }
+  return acc;
+}
+
+// b_fold (HALF floats behind the packed image's caller-provided pointer): W_dir[:, 24:] b_pi -- what point_info's bias contributes to
+// dir_info's pre-activation; k_rays adds it to every ray's start vector (dvec).
+__global__ __launch_bounds__(256) void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg, float* __restrict__ b_fold) {
   // one thread per float4 of the packed image
   const int total = kSegOff.v[nseg];
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total + HALF; idx += gridDim.x * blockDim.x) {
+    if (idx >= total) {  // the HALF extra threads: b_fold
+      const int o = idx - total;
+      const float* dr = w.p[W_DIR] + (size_t)o * (WIDTH + DIR_DIM) + DIR_DIM;
+      const float* bp = w.p[B_PI];
+      float s = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < WIDTH; ++j) s = __builtin_fmaf(dr[j], bp[j], s);
+      if (b_fold) b_fold[o] = s;
+      continue;
+    }
     int s = 0;
 #pragma unroll 1
     while (s + 1 < nseg && idx >= kSegOff.v[s + 1]) ++s;
@@ -82,10 +127,12 @@ __global__ __launch_bounds__(256) void k_pack_weights(Weights24 w, float4* __res
     const int lane = local & 63;
     const int kb = (local >> 6) % kbn;
     const int ft = (local >> 6) / kbn;
-    const PackDesc d = pack_desc(s);
-    const float* W = w.p[d.src];
     const int f = ft * 32 + (lane & 31);
     const int k0 = kb * 8 + 4 * (lane >> 5);
+    if (s == SEG_FOLD) { out[idx] = fold4_k(w.p[W_DIR], w.p[W_PI], f, k0); continue; }    // feature = dir_info row, k = h7 index
+    if (s == SEG_T_FOLD) { out[idx] = fold4_o(w.p[W_DIR], w.p[W_PI], k0, f); continue; }  // feature = h7 index, k = dir_info row
+    const PackDesc d = pack_desc(s);
+    const float* W = w.p[d.src];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!d.transposed) {
       // four consecutive inputs of one output row: one 16-byte load (every row length and column offset is a multiple of 4 floats,
@@ -243,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   STAMP(1);
     // next: L6, L7 or point_info -- consecutive segments of equal size
     wfrag_first<32, 2>(a.wp + seg_off4(SEG_L5) + (size_t)(l - 4) * 8 * 32 * 64, wv * 2, lane, wc);
-    bias_first<2>(l < 7 ? a.w.p[2 * (l + 1) + 1] : a.w.p[B_PI], fbase, lane, bq);
+    if (l < 7) bias_first<2>(a.w.p[2 * (l + 1) + 1], fbase, lane, bq);
     __syncthreads();
   STAMP(2);
     acc_store<2, true>(act, fbase, lane, acc, SAVE ? mk + l * MKS : nullptr);
@@ -269,8 +316,14 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
     scr[wv * 64 + sm] = s;
   }
 
-  // ---- point_info: 256 -> 256, no activation (nerf.py:96, 117)
-  acc_init_regs<2>(bq, acc);
+  // ---- point_info: 256 -> 256, no activation (nerf.py:96, 117).  Its bias enters through the per-ray start vector of dir_info
+  // (dvec includes W_dir[:, 24:] b_pi, common.h SEG_FOLD), so the accumulators start at zero here
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][st][r] = 0.f;
   __builtin_amdgcn_s_setprio(0);
   mfma_layer<32, 2>(a.wp + seg_off4(SEG_PI), wv * 2, act, 0, lane, acc, wc);
   __builtin_amdgcn_s_setprio(2);  // VALU/LDS phases outrank the partner workgroup's MFMA stream
@@ -301,7 +354,6 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
   STAMP(3);
   __syncthreads();
   STAMP(4);
-  if (SAVE) save_rows(act, a.save + S_FEAT * MS, grow0, nrows, 64, WIDTH, tid);
 
   // ---- dir_info: cat(gamma_d, feat) -> 128, ReLU (nerf.py:98, 118)
   f32x16 acd[1][2];
@@ -371,9 +423,9 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
 // ------------------------------------------------------------------------------------------
 // launchers (called from api.cpp)
 // ------------------------------------------------------------------------------------------
-hipError_t launch_pack_weights(const Weights24& w, float4* out, int nseg, hipStream_t st) {
-  const int total = seg_off4(nseg);
-  hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, st, w, out, nseg);
+hipError_t launch_pack_weights(const Weights24& w, float* b_fold, float4* out, int nseg, hipStream_t st) {
+  const int total = seg_off4(nseg) + HALF;
+  hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, st, w, out, nseg, b_fold);
   return hipGetLastError();
 }
 

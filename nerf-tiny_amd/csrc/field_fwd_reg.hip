@@ -8,7 +8,7 @@
 //     accumulator registers of layer L are used, as they stand, as the B operand of layer L+1
 //     (k-step (t, 4g + r): half h supplies k = 32t + 8g + 4h + r), and the A fragment that goes with it is the
 //     4 consecutive weights W[i][32t + 8g + 4h .. +3] -- exactly the float4 the packed image already stores;
-//   * nothing is shared between waves, so nothing synchronises: a wave streams 9,242 MFMAs per tile with a
+//   * nothing is shared between waves, so nothing synchronises: a wave streams 8,256 MFMAs per tile with a
 //     2-stage register pipeline of A fragments (8 x 16-byte loads per k-block, L2/L1 resident, requested one
 //     k-block = 32 MFMAs = 2048 cycles ahead, also across layer boundaries);
 //   * biases enter as one extra MFMA per tile (A = bias, B = 1 on lane half 0); the sigma and colour heads are
@@ -228,13 +228,13 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   reg_layer<32, 8, 8, 8, true, true, SAVE>(wp + seg_off4(SEG_L4A), wp + seg_off4(SEG_L4B), lane, B, A, st0, bv, sv_relu(3));
   reg_layer<8, 8, 32, 8, false, false>(wp + seg_off4(SEG_L4B), sL5, lane, gp, A, st0, nullptr);
   RSTAMP(3);  // layer 4 (1,288 MFMAs)
-  // ---- layers 5..7 (the segment after L7 is point_info: same shape)
+  // ---- layers 5..7 (the segment after L7 is the folded point_info / dir_info layer: 4 tiles)
   bias_load<8>(a.w.p[11], lane, bv);
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5, sL5 + L256, lane, A, B, st0, bv, sv_relu(4));
   bias_load<8>(a.w.p[13], lane, bv);
   reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + L256, sL5 + 2 * L256, lane, B, A, st0, bv, sv_relu(5));
   bias_load<8>(a.w.p[15], lane, bv);
-  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + 2 * L256, wp + seg_off4(SEG_PI), lane, A, B, st0, bv, sv_relu(6));
+  reg_layer<32, 8, 32, 4, true, true, SAVE>(sL5 + 2 * L256, wp + seg_off4(SEG_FOLD), lane, A, B, st0, bv, sv_relu(6));
   RSTAMP(4);  // layers 5..7 (3,096 MFMAs)
   // ---- sigma head on h7 = relu(B) (VALU): sigma = |w_sigma . h7 + b|  (nerf.py:94, 115)
   {
@@ -270,10 +270,8 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
     }
   }
   RSTAMP(5);  // sigma head
-  // ---- point_info: 256 -> 256, no activation; next segment = dir_info (4 tiles)
-  bias_load<8>(a.w.p[B_PI], lane, bv);
-  reg_layer<32, 8, 32, 4, true, true, SAVE>(wp + seg_off4(SEG_PI), wp + seg_off4(SEG_DIR), lane, B, A, st0, bv, sv_relu(7));
-  // ---- dir_info: cat(gamma_d, feat) -> 128, ReLU.  gamma_d part + bias = dvec (per ray), the accumulator start
+  // ---- point_info (256 -> 256, no activation) and dir_info's feature columns as ONE 128 x 256 layer on h7 (common.h SEG_FOLD):
+  // c = relu(W_fold h7 + dvec), dvec (per ray) = b_dir + W_dir[:, :24] gamma_d + W_dir[:, 24:] b_pi = the accumulator start
   {
     const float* dv = a.dvec + (size_t)ray * HALF + 4 * h;
 #pragma unroll
@@ -281,14 +279,14 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 q = *reinterpret_cast<const float4*>(dv + 32 * f + 8 * g);
-        B[f][4 * g + 0] = q.x;
-        B[f][4 * g + 1] = q.y;
-        B[f][4 * g + 2] = q.z;
-        B[f][4 * g + 3] = q.w;
+        A[f][4 * g + 0] = q.x;
+        A[f][4 * g + 1] = q.y;
+        A[f][4 * g + 2] = q.z;
+        A[f][4 * g + 3] = q.w;
       }
   }
-  reg_layer<32, 4, 32, 4, false, false, SAVE>(wp + seg_off4(SEG_DIR), nullptr, lane, A, B, st0, nullptr, sv_rows(S_FEAT));
-  RSTAMP(6);  // point_info + dir_info (1,544 MFMAs = 98,816 cycles)
+  reg_layer<32, 4, 32, 4, false, true, SAVE>(wp + seg_off4(SEG_FOLD), nullptr, lane, B, A, st0, nullptr, sv_relu(7));
+  RSTAMP(6);  // point_info + dir_info folded (512 MFMAs)
   // ---- colour head (VALU): rgb = sigmoid(W_c relu(.) + b)  (nerf.py:99, 119)
   {
     const float* wc = a.w.p[W_COLOR] + 4 * h;
@@ -300,8 +298,8 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
         const float4 q0 = *reinterpret_cast<const float4*>(wc + 32 * t + 8 * g);
         const float4 q1 = *reinterpret_cast<const float4*>(wc + HALF + 32 * t + 8 * g);
         const float4 q2 = *reinterpret_cast<const float4*>(wc + 2 * HALF + 32 * t + 8 * g);
-        const float c0 = relu1(B[t][4 * g + 0]), c1 = relu1(B[t][4 * g + 1]);
-        const float c2 = relu1(B[t][4 * g + 2]), c3 = relu1(B[t][4 * g + 3]);
+        const float c0 = relu1(A[t][4 * g + 0]), c1 = relu1(A[t][4 * g + 1]);
+        const float c2 = relu1(A[t][4 * g + 2]), c3 = relu1(A[t][4 * g + 3]);
         if (SAVE) *reinterpret_cast<float4*>(srow + S_C * MS + 32 * t + 8 * g) = make_float4(c0, c1, c2, c3);
         z0 = __builtin_fmaf(c3, q0.w, __builtin_fmaf(c2, q0.z, __builtin_fmaf(c1, q0.y, __builtin_fmaf(c0, q0.x, z0))));
         z1 = __builtin_fmaf(c3, q1.w, __builtin_fmaf(c2, q1.z, __builtin_fmaf(c1, q1.y, __builtin_fmaf(c0, q1.x, z1))));

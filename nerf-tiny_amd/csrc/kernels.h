@@ -104,7 +104,7 @@ struct MergeArgs {
   float* C_fine;   // [B][3]
 };
 
-hipError_t launch_pack_weights(const Weights24& w, float* fold, float4* out, int nseg, hipStream_t st);  // fold: FOLD_FLOATS scratch (written first)
+hipError_t launch_pack_weights(const Weights24& w, float* b_fold, float4* out, int nseg, hipStream_t st);  // b_fold: HALF floats (common.h SEG_FOLD)
 hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st);
@@ -180,6 +180,19 @@ struct DwBatch {
   int n;
   const float* slabs;
 };
+
+// gradients of point_info and of dir_info's feature columns from the folded product (dw_f32.hip: k_fold_grads)
+struct FoldGradArgs {
+  const float* M;        // [128][256] sum_m dpre_dir[m] (x) h7[m]
+  const float* db_dir;   // [128] (final)
+  const float* w_dir;    // [128][280]
+  const float* w_pi;     // [256][256]
+  const float* b_pi;     // [256]
+  float* dW_pi;          // [256][256]
+  float* db_pi;          // [256]
+  float* dW_dir;         // [128][280], columns 24.. written
+};
+hipError_t launch_fold_grads(const FoldGradArgs& a, hipStream_t st);
 
 struct MergeBwdArgs {
   const float* dC_f;       // [B][3]

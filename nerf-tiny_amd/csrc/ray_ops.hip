@@ -104,6 +104,7 @@ __global__ __launch_bounds__(128) void k_rays(const RaysArgs a) {
     float s = a.b_dir[tid];
 #pragma unroll
     for (int k = 0; k < DIR_DIM; ++k) s = __builtin_fmaf(wr[k], gd[k], s);
+    if (a.b_fold) s += a.b_fold[tid];  // point_info's bias through dir_info's feature columns (common.h SEG_FOLD)
     a.dvec[(size_t)ray * HALF + tid] = s;
   }
 }

@@ -26,8 +26,8 @@ if tile:
     names = ["encode/prologue", "mfma loops", "barrier after mfma", "acc_store", "barrier after store", "heads+rest"]
     ideal = [0, 4608 * 64, 0, 0, 0, 0]
 else:
-    names = ["prologue (loads, point, encode)", "layer 0", "layers 1-3", "layer 4", "layers 5-7", "sigma head", "point_info + dir_info", "colour head + stores"]
-    ideal = [0, 264 * 64, 3096 * 64, 1288 * 64, 3096 * 64, 0, 1544 * 64, 0]
+    names = ["prologue (loads, point, encode)", "layer 0", "layers 1-3", "layer 4", "layers 5-7", "sigma head", "point_info + dir_info (folded)", "colour head + stores"]
+    ideal = [0, 264 * 64, 3096 * 64, 1288 * 64, 3096 * 64, 0, 512 * 64, 0]
 n = v[7] if tile else v[31]; tot = sum(v[:len(names)])  # (the LDS-tile kernel keeps its count at word 7)
 if n == 0:
     raise SystemExit("no stamps recorded: run with NERF_HIP_LIB=nerf-tiny_amd/libnerf_hip_stamps.so (make -C nerf-tiny_amd/csrc stamps)")

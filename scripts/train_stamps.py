@@ -29,12 +29,12 @@ def show(title, vals, n, names, mf):
     print(f"{title}: tiles {n}, cycles/tile {tot / n:.0f}")
     for nm, x, k in zip(names, vals, mf):
         print(f"  {nm:34s} {x / n:9.0f} cycles {100 * x / tot:5.1f} %   MFMA issue {k * 64:7d}  ratio {x / n / max(k * 64, 1):.3f}")
-show("forward with saves (both passes)", v[0:8], v[31], ["prologue", "layer 0", "layers 1-3", "layer 4", "layers 5-7", "sigma head", "point_info + dir_info", "colour head"],
-     [0, 264, 3096, 1288, 3096, 0, 1544, 0])
-show("backward chain, coarse", v[32:39], v[63], ["prologue (colour head)", "dir_info", "point_info + sigma", "layers 7-5", "layer 4", "layers 3-1", "epilogue"],
-     [0, 512, 1032, 3072, 1024, 3072, 0])
-show("backward chain, fine", v[40:47], v[62], ["prologue (colour head)", "dir_info", "point_info + sigma", "layers 7-5", "layer 4 (+skip)", "layers 3-1", "layer 0 + d t"],
-     [0, 512, 1032, 3072, 1280, 3072, 128])
+show("forward with saves (both passes)", v[0:8], v[31], ["prologue", "layer 0", "layers 1-3", "layer 4", "layers 5-7", "sigma head", "point_info + dir_info (folded)", "colour head"],
+     [0, 264, 3096, 1288, 3096, 0, 512, 0])
+show("backward chain, coarse", v[32:39], v[63], ["prologue (colour head)", "dir_info + point_info (folded) + sigma", "-", "layers 7-5", "layer 4", "layers 3-1", "epilogue"],
+     [0, 520, 0, 3072, 1024, 3072, 0])
+show("backward chain, fine", v[40:47], v[62], ["prologue (colour head)", "dir_info + point_info (folded) + sigma", "-", "layers 7-5", "layer 4 (+skip)", "layers 3-1", "layer 0 + d t"],
+     [0, 520, 0, 3072, 1280, 3072, 128])
 # k_dw4 of layer 1 (a 256 x 256 product): per-wave records
 rec = torch.tensor(v[64:64 + 256 * 8 * 4]).view(256, 8, 4)[:, :4]  # k_dw4: four waves per workgroup (record slots 4..7 unused)
 t0 = rec[:, :, 0].min()

@@ -50,27 +50,31 @@ def main():
             loss = run.model.ray_loss(Cc, Cf, pix)
             loss.backward()
             view = lambda name, shape, dt=None: _abi.ws_view(run.model.last_workspace, B, Nc, Nf, _abi.SAVE_FOR_BACKWARD, name, shape, dt)
-            save, G, dz = view("save", (11, MS, 256)), view("G", (10, MS, 256)), view("dz", (Mtot, 4))
+            save, G, dz = view("save", (10, MS, 256)), view("G", (9, MS, 256)), view("dz", (Mtot, 4))
             X = lambda t: save[t, :Mtot]
             Gt = lambda t: G[t, :Mtot]
             g = {k: p.grad for k, p in run.model.network.named_parameters()}
-            chk = [("point_layer.0.0.weight", g["point_layer.0.0.weight"], (Gt(0).T @ X(10))[:, :60]),
+            chk = [("point_layer.0.0.weight", g["point_layer.0.0.weight"], (Gt(0).T @ X(9))[:, :60]),
                    ("point_layer.0.0.bias", g["point_layer.0.0.bias"], Gt(0).sum(0))]
             for l in range(1, 8):
                 full = Gt(l).T @ X(l - 1)
                 if l == 4:
-                    full = torch.cat((full, (Gt(4).T @ X(10))[:, :60]), 1)
+                    full = torch.cat((full, (Gt(4).T @ X(9))[:, :60]), 1)
                 chk.append((f"point_layer.{l}.0.weight", g[f"point_layer.{l}.0.weight"], full))
                 chk.append((f"point_layer.{l}.0.bias", g[f"point_layer.{l}.0.bias"], Gt(l).sum(0)))
-            chk.append(("point_info.weight", g["point_info.weight"], Gt(8).T @ X(7)))
-            chk.append(("point_info.bias", g["point_info.bias"], Gt(8).sum(0)))
-            chk.append(("dir_info.0.weight[:,24:]", g["dir_info.0.weight"][:, 24:], (Gt(9).T @ X(8))[:128]))
-            chk.append(("dir_info.0.bias", g["dir_info.0.bias"], Gt(9).sum(0)[:128]))
-            gd9 = G[9]
+            # point_info folded into dir_info (csrc/common.h SEG_FOLD)
+            sd = run.model.network.state_dict()
+            Wd, Wp, bp = sd["dir_info.0.weight"], sd["point_info.weight"], sd["point_info.bias"]
+            Mfold, dbd = (Gt(8).T @ X(7))[:128], Gt(8).sum(0)[:128]
+            chk.append(("point_info.weight", g["point_info.weight"], Wd[:, 24:].T @ Mfold))
+            chk.append(("point_info.bias", g["point_info.bias"], Wd[:, 24:].T @ dbd))
+            chk.append(("dir_info.0.weight[:,24:]", g["dir_info.0.weight"][:, 24:], Mfold @ Wp.T + torch.outer(dbd, bp)))
+            chk.append(("dir_info.0.bias", g["dir_info.0.bias"], dbd))
+            gd9 = G[8]
             raysum = gd9[:B * Nc].view(B, Nc, 256)[:, :, :128].sum(1) + gd9[B * Nc:Mtot].view(B, Nf, 256)[:, :, :128].sum(1)
             chk.append(("per-ray sums of dpre_dir (sbuf)", view("sbuf", (2, B, 128)).sum(0), raysum))
             chk.append(("dir_info.0.weight[:,:24]", g["dir_info.0.weight"][:, :24], raysum.T @ view("gdbuf", (B, 24))))
-            chk.append(("color_layer.0.weight", g["color_layer.0.weight"], dz[:, :3].T @ X(9)[:, :128]))
+            chk.append(("color_layer.0.weight", g["color_layer.0.weight"], dz[:, :3].T @ X(8)[:, :128]))
             chk.append(("color_layer.0.bias", g["color_layer.0.bias"], dz[:, :3].sum(0)))
             chk.append(("sigma_layer.0.weight", g["sigma_layer.0.weight"], dz[:, 3:4].T @ X(7)))
             chk.append(("sigma_layer.0.bias", g["sigma_layer.0.bias"], dz[:, 3].sum().reshape(1)))
