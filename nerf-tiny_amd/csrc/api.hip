@@ -130,6 +130,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
       L.bmask = take(wb * BM_LAYERS * 1024);
       L.bG = take(wb * BG_TOTAL_KS * BF_FRAG_BYTES);
       L.bslabs = take(dw_bf16_slab_floats() * 4);
+      L.mbuf = take((size_t)HALF * WIDTH * 4);
     } else {
       L.save = take((size_t)NSAVE * (Mtot + DUMP_ROWS) * WIDTH * 4);  // + dump rows (kernels.h: MSrows)
       L.masks = take((size_t)8 * tiles * 4 * 256 * 2);
@@ -271,8 +272,9 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ProfChain pc;  // the phases below follow each other with nothing in between
   if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED)) {
     ProfScope ps(NERF_HIP_K_PACK, st, &pc);
-    if (bf16 && bf16x) HIP_TRY(launch_pack_weights_bf16x(w, at<unsigned char>(ws, L.packed_bf), st));
-    else if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
+    if (bf16) HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));  // fp32 W_fold, b_fold for the bf16 packers (bf16_common.h)
+    if (bf16 && bf16x) HIP_TRY(launch_pack_weights_bf16x(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
+    else if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
     else HIP_TRY(launch_pack_weights(w, at<float>(ws, L.fold), at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
   }
 
@@ -413,7 +415,8 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
   float* G = at<float>(ws, L.G);
   const int wb_c = (int)wave_blocks(B, Nc), wb_tot = wb_c + (int)wave_blocks(B, Nf);
   ProfChain pc;  // the phases below follow each other with nothing in between
-  if (bf16) { ProfScope ps(NERF_HIP_K_PACK, st, &pc); HIP_TRY(launch_pack_weights_bf16_bwd(w, at<unsigned char>(ws, L.packed_bf_bwd), st)); }
+  // (the fp32 fold of the forward call is still in the workspace: backward runs on the weights its forward ran on)
+  if (bf16) { ProfScope ps(NERF_HIP_K_PACK, st, &pc); HIP_TRY(launch_pack_weights_bf16_bwd(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf_bwd), st)); }
 
   // 1. merged composite + per-channel sort backward (nerf.py:302-321)
   MergeBwdArgs mb;
@@ -489,14 +492,18 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     // layer 4: one pass over dpre4 for both column groups of the [256][316] matrix: X = [h3 | gamma_p]
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
     HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9], st));
-    // point_info, and in the same pass over h7 the sigma head: row 3 of h7^T (dz, dspre)
-    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_PI), 16, X(BS_H0 + 7), 16, nullptr, 0, Gt(BG_Z), wb_tot, slabs, &ns, st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 288, 256, 0, 256, 0, WIDTH, dw[W_PI], WIDTH, 0, dw[B_PI], st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 288, 256, 256 + 3, 1, 0, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr, st));
-    // dir_info: X = [gamma_d | feat] (24 of the first 32 columns are real)
-    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_D), 8, X(BS_GD), 2, X(BS_FEAT), 16, nullptr, wb_tot, slabs, &ns, st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 128, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR], st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 128, 288, 0, HALF, 32, WIDTH, dw[W_DIR], WIDTH + DIR_DIM, DIR_DIM, nullptr, st));
+    // point_info folded into dir_info (bf16_common.h): ONE product dpre_dir^T [gamma_d | h7] -- columns 0..23 are dir_info's direction
+    // columns, columns 32.. are M = dpre_dir^T h7 (-> k_fold_grads below) -- and in the same pass over h7 the sigma head: row 3 of h7^T (dz, dspre)
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR], st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 160, 288, 0, HALF, 32, WIDTH, at<float>(ws, L.mbuf), WIDTH, 0, nullptr, st));
+    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 160, 288, HALF + 3, 1, 32, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr, st));
+    {
+      FoldGradArgs fg;
+      fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
+      fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
+      HIP_TRY(launch_fold_grads(fg, st));
+    }
     // colour head = rows 0..2 of the (dz, dspre) tile against c; row 3 of its column sums = the sigma bias gradient
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
     HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR], st));
@@ -631,7 +638,8 @@ int nerf_hip_field_bf16(const float* const* weights24, const int64_t* row, const
   if (int rc = check_device()) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const Weights24 w = as_w24(weights24);
-  HIP_TRY(launch_pack_weights_bf16(w, at<unsigned char>(ws, L.packed_bf), st));
+  HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));
+  HIP_TRY(launch_pack_weights_bf16(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
   RaysArgs ra;
   memset(&ra, 0, sizeof(ra));
   ra.row = row; ra.col = col; ra.pb = poses_bound;

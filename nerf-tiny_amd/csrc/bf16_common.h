@@ -24,49 +24,51 @@ constexpr int BF_FRAG_BYTES = 1024;
 constexpr int BF_CHUNK = 16;              // fragments per LDS ring slot (16 KiB)
 constexpr int BF_BIAS_BYTES = 16384;      // bias block (78 tiles x 32 floats used)
 
-// stream segments: first fragment, output tiles, k-steps
+// stream segments: first fragment, output tiles, k-steps.  point_info (no activation, nerf.py:117) is folded into dir_info's feature
+// columns (common.h SEG_FOLD): W_fold = W_dir[:, 24:] W_pi is formed in fp32 (k_fold_weights) and rounded to bf16 ONCE; the sigma
+// head is a tile of its own on h7.
 constexpr int BFS_L0 = 0;      // 8 tiles x 4   gamma_p (60 -> 64)
 constexpr int BFS_L1 = 32;     // 8 x 16, likewise L2, L3
 constexpr int BFS_L4 = 416;    // 8 x (16 hidden + 4 gamma_p)   (nerf.py:109: hidden first)
 constexpr int BFS_L5 = 576;    // 8 x 16, likewise L6, L7
-constexpr int BFS_PI = 960;    // 9 x 16: point_info tiles 0..7, tile 8 row 0 = sigma_layer
-constexpr int BFS_DIR = 1104;  // 4 x (2 gamma_d (24 -> 32) + 16 feat)   (nerf.py:117: direction first)
-constexpr int BFS_COL = 1176;  // 1 x 8: rows 0..2 = color_layer
-constexpr int BF_NFRAG = 1184;
-constexpr int BF_NCHUNK = BF_NFRAG / BF_CHUNK;  // 74
+constexpr int BFS_SIG = 960;   // 1 x 16: row 0 = sigma_layer (on h7)
+constexpr int BFS_DIR = 976;   // 4 x (2 gamma_d (24 -> 32) + 16 h7 through W_fold)   (nerf.py:117: direction first)
+constexpr int BFS_COL = 1048;  // 1 x 8: rows 0..2 = color_layer
+constexpr int BF_NFRAG = 1056;
+constexpr int BF_NCHUNK = BF_NFRAG / BF_CHUNK;  // 66
 static_assert(BF_NCHUNK * BF_CHUNK == BF_NFRAG, "stream must be whole chunks");
 constexpr size_t BF_IMAGE_BYTES = (size_t)BF_BIAS_BYTES + (size_t)BF_NFRAG * BF_FRAG_BYTES;
 
 // ---- backward (dX chain) stream: transposed weights, consumed from the colour head back to layer 0 --------------------
-//  COLT 4 tiles x 4 k-steps (only k-step 0, inputs 0..2 = dz, are non-zero)        d c    = W_color^T dz
-//  DIRT 8 x 8                                                                     d feat = W_dir[:, 24:]^T dpre_dir
-//  PIT  8 x 17: 16 k-steps W_PI^T dfeat + 1 k-step w_sigma (input slot 3 = dspre)  d h7
+//  COLT  4 tiles x 4 k-steps (only k-step 0, inputs 0..2 = dz, are non-zero)       d c    = W_color^T dz
+//  FOLDT 8 x 9: 8 k-steps W_fold^T dpre_dir + 1 k-step w_sigma (input slot 3 = dspre)   d h7
 //  L7T, L6T, L5T, L4T (hidden columns), L3T, L2T, L1T: 8 x 16 each
 //  fine pass only, d gamma_p:  G0T 2 x 16 = W_0^T (input dpre0),  G4T 2 x 16 = W_4[:, 256:]^T (input dpre4, re-read)
 // One image serves both passes: the coarse pass stops after L1T.
-constexpr int BBS_COLT = 0, BBS_DIRT = 16, BBS_PIT = 80, BBS_L7T = 216, BBS_L4T = 600, BBS_L3T = 728;
-constexpr int BBS_G0T = 1112, BBS_G4T = 1144;
-constexpr int BBC_NFRAG = 1112, BBF_NFRAG = 1176;
+constexpr int BBS_COLT = 0, BBS_FOLDT = 16, BBS_L7T = 88, BBS_L4T = 472, BBS_L3T = 600;
+constexpr int BBS_G0T = 984, BBS_G4T = 1016;
+constexpr int BBC_NFRAG = 984, BBF_NFRAG = 1048;
 constexpr int BBC_NCHUNK = (BBC_NFRAG + BF_CHUNK - 1) / BF_CHUNK, BBF_NCHUNK = (BBF_NFRAG + BF_CHUNK - 1) / BF_CHUNK;
 constexpr size_t BB_IMAGE_BYTES = (size_t)BF_BIAS_BYTES + (size_t)BBF_NCHUNK * BF_CHUNK * BF_FRAG_BYTES;
 
 // ---- training buffers in FRAGMENT layout: per wave block (32 consecutive samples of a pass) and tensor, ks pieces of
 // 1 KiB = what the wave's 64 lanes hold as one packed B operand (lane (j, h): sample j, features 16ks + 4h + {0..3, 8..11}).
 // Tensor-major: tensor t starts at wb_tot * 1024 * cum_ks(t); piece (wb, ks) of it at ((wb * ks_t) + ks) * 1024.
-// saved by the forward:
-constexpr int BS_GP = 0, BS_H0 = 1, BS_FEAT = 9, BS_C = 10, BS_GD = 11, NBS = 12;
-__host__ __device__ constexpr int bs_ks(int t) { return t == BS_GP ? 4 : t <= BS_FEAT ? 16 : t == BS_C ? 8 : 2; }
+// saved by the forward (point_info's output is not: folded, no weight gradient needs it):
+constexpr int BS_GP = 0, BS_H0 = 1, BS_C = 9, BS_GD = 10, NBS = 11;
+__host__ __device__ constexpr int bs_ks(int t) { return t == BS_GP ? 4 : t < BS_C ? 16 : t == BS_C ? 8 : 2; }
 __host__ __device__ constexpr int bs_cum(int t) { int o = 0; for (int i = 0; i < t; ++i) o += bs_ks(i); return o; }
-constexpr int BS_TOTAL_KS = bs_cum(NBS);  // 158 KiB per wave block
+constexpr int BS_TOTAL_KS = bs_cum(NBS);  // 142 KiB per wave block
 // written by the backward chain (pre-activation gradients = A operands of the dW GEMMs):
-constexpr int BG_L0 = 0, BG_PI = 8, BG_D = 9, BG_Z = 10, NBG = 11;  // BG_Z: features 0..2 = dz (colour), 3 = dspre (sigma)
-__host__ __device__ constexpr int bg_ks(int t) { return t <= BG_PI ? 16 : t == BG_D ? 8 : 2; }  // BG_Z: 2nd piece = zeros
+constexpr int BG_L0 = 0, BG_D = 8, BG_Z = 9, NBG = 10;  // BG_Z: features 0..2 = dz (colour), 3 = dspre (sigma)
+__host__ __device__ constexpr int bg_ks(int t) { return t < BG_D ? 16 : t == BG_D ? 8 : 2; }  // BG_Z: 2nd piece = zeros
 __host__ __device__ constexpr int bg_cum(int t) { int o = 0; for (int i = 0; i < t; ++i) o += bg_ks(i); return o; }
-constexpr int BG_TOTAL_KS = bg_cum(NBG);  // 154
+constexpr int BG_TOTAL_KS = bg_cum(NBG);  // 138
 // ReLU "alive" masks: u16 [9 layers: h0..h7, c][wb_tot][64 lanes][8 tiles], bit 15-r = accumulator register r >= +0
 constexpr int BM_LAYERS = 9;
 
 // bias tiles (32 floats each) in the bias block
-constexpr int BFB_L0 = 0, BFB_PI = 64, BFB_SIGMA = 72, BFB_DIR = 73, BFB_COL = 77, BF_NBIAS_TILES = 78;
+constexpr int BFB_L0 = 0, BFB_SIGMA = 64, BFB_DIR = 65, BFB_COL = 69, BF_NBIAS_TILES = 70;  // BFB_DIR: b_dir + W_dir[:, 24:] b_pi
+
 
 }  // namespace nerf

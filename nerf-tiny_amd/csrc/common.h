@@ -62,8 +62,9 @@ __device__ __constant__ const uint32_t kFreqDirBits[4] = {0x40490fdbu, 0x40fd527
 enum { W_L0 = 0, B_L0 = 1, W_SIGMA = 16, B_SIGMA = 17, W_PI = 18, B_PI = 19, W_DIR = 20, B_DIR = 21, W_COLOR = 22, B_COLOR = 23 };
 
 struct Weights24 { const float* p[24]; };
-// b_fold[128] = W_dir[:, 24:] b_pi in the workspace (k_pack_weights; k_rays adds it to every ray's dir_info start vector)
-constexpr int FOLD_FLOATS = HALF;
+// fp32 scratch of the fold in the workspace: b_fold[128] = W_dir[:, 24:] b_pi (k_pack_weights / k_fold_weights; k_rays adds it to every
+// ray's dir_info start vector), then -- bf16-MLP variant only, k_fold_weights -- W_fold[128][256] for the bf16 packers to round
+constexpr int FOLD_FLOATS = HALF + HALF * WIDTH;
 struct Grads24 { float* p[24]; };
 
 // ---- workspace carve-up (host side, api.cpp) ----

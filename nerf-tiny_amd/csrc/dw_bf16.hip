@@ -33,7 +33,8 @@ struct DwBfArgs {
   const unsigned char* X1[6];  // input tensor(s): the i index runs over X1's x1_ks pieces, then X2's (2 * NIT - x1_ks)
   const unsigned char* X2;     // (single products only)
   int ngemm;
-  const unsigned char* Z;   // HAS_Z: a second, 2-piece gradient tensor whose product with X is formed as well (X^T Z)
+  const unsigned char* Z;   // HAS_Z: a second, 2-piece gradient tensor whose product with the X tiles z_tile0 .. z_tile0 + 7 is formed as well (X^T Z)
+  int z_tile0;
   int g_ks, o_tiles;        // o_tiles = output row tiles (waves w >= o_tiles only help loading)
   int x1_ks;
   int wb_tot;
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
   const int b_lo = wg * per, b_hi = min(a.wb_tot, b_lo + per);
   const int nb = b_hi - b_lo;
   const int gks = a.g_ks, x1 = a.x1_ks, total = gks + XKS + (HAS_Z ? 2 : 0);
-  const bool worker = wv < a.o_tiles, zworker = HAS_Z && wv < NIT;
+  const bool worker = wv < a.o_tiles, zworker = HAS_Z && a.z_tile0 + wv < NIT;
+  const int zt = a.z_tile0 + wv;  // the X tile this wave multiplies with Z
 
   f32x16 acc[NIT], accb, accz;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
       if (zworker) {  // rows = this wave's X tile, columns = Z features: (X^T Z) tile
         const unsigned char* zb = xb + XKS * BF_FRAG_BYTES;
 #pragma unroll
-        for (int kstep = 0; kstep < 2; ++kstep) accz = bf_mfma(dwb_operand(xb, wv, kstep, lane), dwb_operand(zb, 0, kstep, lane), accz);
+        for (int kstep = 0; kstep < 2; ++kstep) accz = bf_mfma(dwb_operand(xb, zt, kstep, lane), dwb_operand(zb, 0, kstep, lane), accz);
       }
     }
     wait_vmcnt<0>();  // nothing may still be writing this workgroup's LDS when it ends
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
   if (zworker) {  // slab row o_tiles*32 + z, column i
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int i = 32 * zt + (r & 3) + 8 * (r >> 2) + 4 * hh;
       slab[(size_t)(a.o_tiles * 32 + n) * ld + i] = accz[r];
     }
   }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void k_dw_bf16_reduce(const DwBfReduceArgs a) 
   }
 }
 
-size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * (256 + 32) * (320 + 1); }  // also covers 6 x 42 slabs of 256 x 257
+size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * (256 + 32) * (320 + 1); }  // also covers 6 x 42 slabs of 256 x 257 and (128 + 32) x 289
 
 template <int NIT, bool HAS_Z>
 static hipError_t dwb_launch(const DwBfArgs& a, int wgs, hipStream_t st) {
@@ -231,11 +233,12 @@ hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned 
                                const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st) {
   DwBfArgs a;
   memset(&a, 0, sizeof(a));
+  a.z_tile0 = Z ? x1_ks / 2 : 0;  // Z multiplies the X2 tiles (the sigma head rides on the product whose second input tensor is h7)
   a.G[0] = G; a.X1[0] = X1; a.ngemm = 1; a.X2 = X2 ? X2 : X1; a.Z = Z; a.g_ks = g_ks; a.o_tiles = (g_ks + 1) / 2; a.x1_ks = x1_ks; a.wb_tot = wb_tot; a.slabs = slabs;
   const int wgs = wb_tot < DWB_WGS ? wb_tot : DWB_WGS;
   *nslab = wgs;
   const int xks = x1_ks + x2_ks;
-  if (Z) return xks == 16 ? dwb_launch<8, true>(a, wgs, st) : hipErrorInvalidValue;
+  if (Z) return xks == 18 ? dwb_launch<9, true>(a, wgs, st) : xks == 16 ? dwb_launch<8, true>(a, wgs, st) : hipErrorInvalidValue;
   switch (xks) {
     case 20: return dwb_launch<10, false>(a, wgs, st);
     case 18: return dwb_launch<9, false>(a, wgs, st);

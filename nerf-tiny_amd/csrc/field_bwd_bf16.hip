@@ -3,7 +3,7 @@
 // Mirror image of field_fwd_bf16.hip on the same machinery (bf16_stream.h): a wave owns 32 samples, the stream now holds
 // the TRANSPOSED weights from the colour head back to layer 0, and the fp32 accumulator of "d input" of one layer,
 // masked with the layer's saved ReLU bits and rounded to bf16, is the B operand of the next (earlier) layer:
-//     dz -> dc -> dpre_dir -> dfeat -> dh7 (+ w_sigma dspre) -> dpre7 -> ... -> dpre0 [-> d gamma_p -> dt, fine pass]
+//     dz -> dc -> dpre_dir -> dh7 (W_fold^T: point_info folded into dir_info; + w_sigma dspre) -> dpre7 -> ... -> dpre0 [-> d gamma_p -> dt, fine pass]
 // Every masked accumulator (= pre-activation gradient, the A operand of that layer's dW GEMM in dw_bf16.hip) is also
 // written to the gradient buffer in fragment layout (bf16_common.h), 1 KiB per store instruction.
 // The wave's ReLU masks (9 layers x 8 tiles x 64 lanes x u16 = 9 KiB) are brought to LDS once, by the same direct-to-LDS
@@ -29,7 +29,7 @@ struct BwdStream {
   static constexpr int PROLOGUE_STORES = 2;  // the dz / dspre fragment and its zero partner
   static constexpr int L3T = BBS_L3T;
   static constexpr BfStoreTable<NFRAG> make() {
-    const BwdTiles tiles[] = {{BBS_COLT, 4, 4, 8},        {BBS_DIRT, 8, 8, 16},       {BBS_PIT, 8, 17, 16},     {BBS_L7T, 8, 16, 16},
+    const BwdTiles tiles[] = {{BBS_COLT, 4, 4, 8},        {BBS_FOLDT, 8, 9, 16},      {BBS_L7T, 8, 16, 16},
                               {BBS_L7T + 128, 8, 16, 16}, {BBS_L7T + 256, 8, 16, 16}, {BBS_L4T, 8, 16, 16},     {L3T, 8, 16, 16},
                               {L3T + 128, 8, 16, 16},     {L3T + 256, 8, 16, 16}};  // the d gamma_p tiles store nothing
     BfStoreTable<NFRAG> t{};
@@ -135,19 +135,18 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
 
   // colour head: dc = W_color^T dz, through c's ReLU -> dpre_dir
   bf_segment<S, BBS_COLT, 4, 4, 0, -1, 0, -1>(c, fr, acc, zin, nullptr, grad_to(Y, BG_D, 8, 4), nothing);
-  // dir_info: dfeat = W_dir[:, 24:]^T dpre_dir (point_info has no activation)
-  bf_segment<S, BBS_DIRT, 8, 8, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_PI, -1), last_of(grad_to(Y, BG_D, 8, 4), 3));
-  // point_info + sigma head: dh7 = W_PI^T dfeat + w_sigma dspre, through h7's ReLU
-  bf_segment<S, BBS_PIT, 8, 16, 1, -1, 0, -1>(c, fr, acc, X, zin, grad_to(Y, BG_L0 + 7, 7), last_of(grad_to(X, BG_PI, -1), 7));
-  bf_segment<S, BBS_L7T, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 6, 6), last_of(grad_to(Y, BG_L0 + 7, 7), 7));
-  bf_segment<S, BBS_L7T + 128, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 5, 5), last_of(grad_to(X, BG_L0 + 6, 6), 7));
-  bf_segment<S, BBS_L7T + 256, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 4, 4), last_of(grad_to(Y, BG_L0 + 5, 5), 7));
-  bf_segment<S, BBS_L4T, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 3, 3), last_of(grad_to(X, BG_L0 + 4, 4), 7));
-  bf_segment<S, BBS_L3T, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 2, 2), last_of(grad_to(Y, BG_L0 + 3, 3), 7));
-  bf_segment<S, BBS_L3T + 128, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 1, 1), last_of(grad_to(X, BG_L0 + 2, 2), 7));
-  bf_segment<S, BBS_L3T + 256, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 0, 0), last_of(grad_to(Y, BG_L0 + 1, 1), 7));
+  // dir_info and point_info as ONE transposed layer (point_info has no activation: folded, bf16_common.h) + the sigma head:
+  // dh7 = W_fold^T dpre_dir + w_sigma dspre, through h7's ReLU
+  bf_segment<S, BBS_FOLDT, 8, 8, 1, -1, 0, -1>(c, fr, acc, Y, zin, grad_to(X, BG_L0 + 7, 7), last_of(grad_to(Y, BG_D, 8, 4), 3));
+  bf_segment<S, BBS_L7T, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 6, 6), last_of(grad_to(X, BG_L0 + 7, 7), 7));
+  bf_segment<S, BBS_L7T + 128, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 5, 5), last_of(grad_to(Y, BG_L0 + 6, 6), 7));
+  bf_segment<S, BBS_L7T + 256, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 4, 4), last_of(grad_to(X, BG_L0 + 5, 5), 7));
+  bf_segment<S, BBS_L4T, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 3, 3), last_of(grad_to(Y, BG_L0 + 4, 4), 7));
+  bf_segment<S, BBS_L3T, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 2, 2), last_of(grad_to(X, BG_L0 + 3, 3), 7));
+  bf_segment<S, BBS_L3T + 128, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 1, 1), last_of(grad_to(Y, BG_L0 + 2, 2), 7));
+  bf_segment<S, BBS_L3T + 256, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 0, 0), last_of(grad_to(X, BG_L0 + 1, 1), 7));
   if constexpr (!FINE) {
-    grad_to(X, BG_L0 + 0, 0)(7, acc[1]);  // the last tile of the stream
+    grad_to(Y, BG_L0 + 0, 0)(7, acc[1]);  // the last tile of the stream
   } else {
     // ---- d gamma_p (fp32) = W_0^T dpre0 + W_4[:, 256:]^T dpre4  (nerf.py:104, 109).  dpre4 is long gone from the
     // registers: the wave reads back the 16 pieces it stored itself ~500 MFMAs ago (complete: every counted wait since
@@ -155,10 +154,10 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
     f32x16 dgp[2];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-      Y[ks] = *reinterpret_cast<const u32x4*>(gvl + ((size_t)a.wb_tot * bg_cum(BG_L0 + 4) + (size_t)wb * 16 + ks) * BF_FRAG_BYTES);
-    bf_segment<S, BBS_G0T, 2, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, [&](int f, const f32x16& A) { dgp[f] = A; },
-                                                last_of(grad_to(X, BG_L0 + 0, 0), 7));
-    bf_segment<S, BBS_G4T, 2, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, [&](int f, const f32x16& A) { dgp[f] += A; },
+      X[ks] = *reinterpret_cast<const u32x4*>(gvl + ((size_t)a.wb_tot * bg_cum(BG_L0 + 4) + (size_t)wb * 16 + ks) * BF_FRAG_BYTES);
+    bf_segment<S, BBS_G0T, 2, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, [&](int f, const f32x16& A) { dgp[f] = A; },
+                                                last_of(grad_to(Y, BG_L0 + 0, 0), 7));
+    bf_segment<S, BBS_G4T, 2, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, [&](int f, const f32x16& A) { dgp[f] += A; },
                                                 [&](const f32x16& A) { dgp[1] = A; });
     dgp[1] += acc[1];
     // gamma -> point -> depth (t_fine is not detached, quirk Q9).  dgp[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of
@@ -198,18 +197,14 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
 // ------------------------------------------------------------------------------------------
 // transposed weight image: fragment (f, ks), lane (i, h), slot s  =  W[out = 16ks + 4h + (s&3) + 8(s>>2)][in = 32f + i]
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bb_weight(const Weights24& w, int frag, int i, int kk) {
-  if (frag < BBS_DIRT) {  // COLT: d c = W_color^T dz
+__device__ __forceinline__ float bb_weight(const Weights24& w, const float* __restrict__ fold, int frag, int i, int kk) {
+  if (frag < BBS_FOLDT) {  // COLT: d c = W_color^T dz
     const int f = frag / 4, ks = frag % 4, k = 16 * ks + kk;
     return k < 3 ? w.p[W_COLOR][(size_t)k * HALF + 32 * f + i] : 0.f;
   }
-  if (frag < BBS_PIT) {  // DIRT
-    const int q = frag - BBS_DIRT, f = q / 8, ks = q % 8, k = 16 * ks + kk;
-    return w.p[W_DIR][(size_t)k * (WIDTH + DIR_DIM) + DIR_DIM + 32 * f + i];
-  }
-  if (frag < BBS_L7T) {  // PIT: 16 k-steps of W_PI^T, then the sigma step (input slot 3)
-    const int q = frag - BBS_PIT, f = q / 17, ks = q % 17, k = 16 * ks + kk;
-    if (ks < 16) return w.p[W_PI][(size_t)k * WIDTH + 32 * f + i];
+  if (frag < BBS_L7T) {  // FOLDT: 8 k-steps of W_fold^T (W_fold = W_dir[:, 24:] W_pi, [128][256]), then the sigma step (input slot 3)
+    const int q = frag - BBS_FOLDT, f = q / 9, ks = q % 9, k = 16 * ks + kk;
+    if (ks < 8) return fold[HALF + (size_t)k * WIDTH + 32 * f + i];
     return kk == 3 ? w.p[W_SIGMA][32 * f + i] : 0.f;
   }
   if (frag < BBS_G0T) {  // L7T .. L1T (layer 4: hidden columns of the [256][316] matrix)
@@ -228,7 +223,7 @@ __device__ __forceinline__ float bb_weight(const Weights24& w, int frag, int i, 
   return 0.f;  // padding up to whole chunks
 }
 
-__global__ __launch_bounds__(256) void k_pack_weights_bf16_bwd(const Weights24 w, unsigned char* __restrict__ img) {
+__global__ __launch_bounds__(256) void k_pack_weights_bf16_bwd(const Weights24 w, const float* __restrict__ fold, unsigned char* __restrict__ img) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= BBF_NCHUNK * BF_CHUNK * 64) return;
   const int frag = gid >> 6, lane = gid & 63, i = lane & 31, h = lane >> 5;
@@ -236,14 +231,14 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16_bwd(const Weights24 w
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int kk = 4 * h + 2 * (q & 1) + 8 * (q >> 1);
-    v[q] = pack2(bb_weight(w, frag, i, kk), bb_weight(w, frag, i, kk + 1));
+    v[q] = pack2(bb_weight(w, fold, frag, i, kk), bb_weight(w, fold, frag, i, kk + 1));
   }
   *reinterpret_cast<u32x4*>(img + BF_BIAS_BYTES + (size_t)frag * BF_FRAG_BYTES + lane * 16) = v;
 }
 
-hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, unsigned char* img, hipStream_t st) {
+hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st) {
   const int threads = BBF_NCHUNK * BF_CHUNK * 64;
-  hipLaunchKernelGGL(k_pack_weights_bf16_bwd, dim3((threads + 255) / 256), dim3(256), 0, st, w, img);
+  hipLaunchKernelGGL(k_pack_weights_bf16_bwd, dim3((threads + 255) / 256), dim3(256), 0, st, w, fold, img);
   return hipGetLastError();
 }
 

@@ -103,6 +103,31 @@ __device__ __forceinline__ float4 fold4_o(const float* __restrict__ wdir, const 
   return acc;
 }
 
+// The fold as a kernel of its own, for the bf16-MLP variant (its packers round W_fold to bf16): fold[0 .. 128) = b_fold,
+// fold[128 + o * 256 + k] = W_fold[o][k].  33 blocks: block b < 32 = rows 4b .. 4b+3 (one row per wave: the W_dir element of a step is
+// wave-uniform, the W_pi row a coalesced KiB), block 32 = b_fold.
+__global__ __launch_bounds__(256) void k_fold_weights(Weights24 w, float* __restrict__ fold) {
+  if (blockIdx.x == 32) {
+    const int o = threadIdx.x;
+    if (o < HALF) {
+      const float* dr = w.p[W_DIR] + (size_t)o * (WIDTH + DIR_DIM) + DIR_DIM;
+      const float* bp = w.p[B_PI];
+      float s = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < WIDTH; ++j) s = __builtin_fmaf(dr[j], bp[j], s);
+      fold[o] = s;
+    }
+    return;
+  }
+  const int o = 4 * blockIdx.x + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), k0 = 4 * (threadIdx.x & 63);
+  *reinterpret_cast<float4*>(fold + HALF + (size_t)o * WIDTH + k0) = fold4_k(w.p[W_DIR], w.p[W_PI], o, k0);
+}
+
+hipError_t launch_fold_weights(const Weights24& w, float* fold, hipStream_t st) {
+  hipLaunchKernelGGL(k_fold_weights, dim3(33), dim3(256), 0, st, w, fold);
+  return hipGetLastError();
+}
+
 // b_fold (HALF floats behind the packed image's caller-provided pointer): W_dir[:, 24:] b_pi -- what point_info's bias contributes to
 // dir_info's pre-activation; k_rays adds it to every ray's start vector (dvec).
 __global__ __launch_bounds__(256) void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg, float* __restrict__ b_fold) {

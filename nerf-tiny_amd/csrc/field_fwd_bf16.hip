@@ -15,7 +15,8 @@
 //     a layer's input and output live as 64 + 64 packed registers, so two waves fit on a SIMD and one wave's VALU work
 //     (encoding, conversions, heads) runs in the shadow of the other's MFMAs;
 //   * biases are fp32 accumulator start values read from LDS; sigma and colour heads are extra MFMA tiles (row 0 / rows
-//     0..2 of a 32-row tile), 24 MFMAs instead of ~400 VALU instructions.
+//     0..2 of a 32-row tile), 24 MFMAs instead of ~400 VALU instructions;
+//   * point_info (no activation) is folded into dir_info's feature columns (bf16_common.h): 128 MFMAs per wave block less.
 #include "bf16_stream.h"
 
 namespace nerf {
@@ -27,7 +28,7 @@ struct FwdTiles { int s0, nft, ks, stores, last_extra; };
 constexpr FwdTiles kFwdTiles[] = {
     {BFS_L0, 8, 4, 0, 17},        {BFS_L1, 8, 16, 0, 17},       {BFS_L1 + 128, 8, 16, 0, 17}, {BFS_L1 + 256, 8, 16, 0, 17},
     {BFS_L4, 8, 20, 0, 17},       {BFS_L5, 8, 16, 0, 17},       {BFS_L5 + 128, 8, 16, 0, 17}, {BFS_L5 + 256, 8, 16, 0, 17},
-    {BFS_PI, 8, 16, 0, 16},       {BFS_PI + 128, 1, 16, 0, 0},  {BFS_DIR, 4, 18, 0, 9},       {BFS_COL, 1, 8, 0, 0}};
+    {BFS_SIG, 1, 16, 0, 0},       {BFS_DIR, 4, 18, 0, 9},       {BFS_COL, 1, 8, 0, 0}};
 constexpr BfStoreTable<BF_NFRAG> make_fwd_store_table() {
   BfStoreTable<BF_NFRAG> t{};
   int ev[BF_NFRAG + 64] = {};
@@ -182,34 +183,20 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   bf_segment<S, BFS_L4, 8, 16, 4, BFB_L0 + 32, 0, BFB_L0 + 40>(c, fr, acc, Y, gp, relu_to(X, BS_H0 + 4, 4), last_of(relu_to(Y, BS_H0 + 3, 3), 7));
   bf_segment<S, BFS_L5, 8, 16, 0, BFB_L0 + 40, 0, BFB_L0 + 48>(c, fr, acc, X, nullptr, relu_to(Y, BS_H0 + 5, 5), last_of(relu_to(X, BS_H0 + 4, 4), 7));
   bf_segment<S, BFS_L5 + 128, 8, 16, 0, BFB_L0 + 48, 0, BFB_L0 + 56>(c, fr, acc, Y, nullptr, relu_to(X, BS_H0 + 6, 6), last_of(relu_to(Y, BS_H0 + 5, 5), 7));
-  bf_segment<S, BFS_L5 + 256, 8, 16, 0, BFB_L0 + 56, 0, BFB_PI>(c, fr, acc, X, nullptr, relu_to(Y, BS_H0 + 7, 7), last_of(relu_to(X, BS_H0 + 6, 6), 7));
-  // ---- point_info (no activation) + sigma head (tile 8, row 0): sigma = |w_sigma . h7 + b|  (nerf.py:94, 113-115)
+  bf_segment<S, BFS_L5 + 256, 8, 16, 0, BFB_L0 + 56, 0, BFB_SIGMA>(c, fr, acc, X, nullptr, relu_to(Y, BS_H0 + 7, 7), last_of(relu_to(X, BS_H0 + 6, 6), 7));
+  // ---- sigma head (one tile, row 0) on h7: sigma = |w_sigma . h7 + b|  (nerf.py:94, 113-115)
   float spre = 0.f;
-  auto pi_epi = [&](int f, const f32x16& A) {
-    if (f < 8) {
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) X[2 * f + mh][q] = pack2(A[8 * mh + 2 * q], A[8 * mh + 2 * q + 1]);
-      if constexpr (SAVE) {
-        if (f == 7) {
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) save_piece(BS_FEAT, ks, X[ks]);
-        }
-      }
-    } else {
-      spre = A[0];
-    }
-  };
-  bf_segment<S, BFS_PI, 9, 16, 0, BFB_PI, 0, BFB_DIR>(c, fr, acc, Y, nullptr, pi_epi, last_of(relu_to(Y, BS_H0 + 7, 7), 7));
-  // ---- dir_info on cat(gamma_d, feat), ReLU (nerf.py:117-118); its first tile also retires the sigma tile
-  bf_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd, X, relu_to(Y, BS_C, 8, 4), last_of(pi_epi, 8));
+  auto sig_epi = [&](const f32x16& A) { spre = A[0]; };
+  bf_segment<S, BFS_SIG, 1, 16, 0, BFB_SIGMA, 0, BFB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y, BS_H0 + 7, 7), 7));
+  // ---- point_info folded into dir_info (bf16_common.h): c = relu(W_dir[:, :24] gamma_d + W_fold h7 + b_dir + W_dir[:, 24:] b_pi)
+  // (nerf.py:117-118); its first tile also retires the sigma tile
+  bf_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd, Y, relu_to(X, BS_C, 8, 4), sig_epi);
   if (valid && h == 0) {
     a.sigma[m] = fabsf(spre);
     if (SAVE) a.spre[a.row0 + m] = spre;
   }
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
-  bf_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y, BS_C, 8, 4), 3));
+  bf_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X, BS_C, 8, 4), 3));
   if (valid && h == 0) {
     a.rgb[(size_t)m * 3 + 0] = 1.0f / (1.0f + expf(-acc[1][0]));
     a.rgb[(size_t)m * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
@@ -220,7 +207,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
 // ------------------------------------------------------------------------------------------
 // weight image
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bf_weight(const Weights24& w, int frag, int i, int kk /* 0..15 inside the k-step */, int h) {
+__device__ __forceinline__ float bf_weight(const Weights24& w, const float* __restrict__ fold, int frag, int i, int kk /* 0..15 inside the k-step */, int h) {
   (void)h;
   if (frag < BFS_L1) {  // L0
     const int f = frag / 4, ks = frag % 4, k = 16 * ks + kk;
@@ -234,34 +221,32 @@ __device__ __forceinline__ float bf_weight(const Weights24& w, int frag, int i, 
     const int q = frag - BFS_L4, f = q / 20, ks = q % 20, k = 16 * ks + kk;
     return (k < WIDTH + POINT_DIM) ? w.p[8][(size_t)(32 * f + i) * (WIDTH + POINT_DIM) + k] : 0.f;
   }
-  if (frag < BFS_PI) {  // L5..L7
+  if (frag < BFS_SIG) {  // L5..L7
     const int r = frag - BFS_L5, l = 5 + r / 128, q = r % 128, f = q / 16, ks = q % 16;
     return w.p[2 * l][(size_t)(32 * f + i) * WIDTH + 16 * ks + kk];
   }
-  if (frag < BFS_DIR) {  // point_info + sigma row
-    const int q = frag - BFS_PI, f = q / 16, ks = q % 16, k = 16 * ks + kk;
-    if (f < 8) return w.p[W_PI][(size_t)(32 * f + i) * WIDTH + k];
+  if (frag < BFS_DIR) {  // sigma row on h7
+    const int ks = frag - BFS_SIG, k = 16 * ks + kk;
     return i == 0 ? w.p[W_SIGMA][k] : 0.f;
   }
-  if (frag < BFS_COL) {  // dir_info: [128][280] = cat(gamma_d (24), feat)
+  if (frag < BFS_COL) {  // dir_info: gamma_d columns of W_dir (24 -> 32), then W_fold = W_dir[:, 24:] W_pi on h7
     const int q = frag - BFS_DIR, f = q / 18, ks = q % 18, k = 16 * ks + kk;
     if (ks < 2) return k < DIR_DIM ? w.p[W_DIR][(size_t)(32 * f + i) * (WIDTH + DIR_DIM) + k] : 0.f;
-    return w.p[W_DIR][(size_t)(32 * f + i) * (WIDTH + DIR_DIM) + DIR_DIM + (k - 32)];
+    return fold[HALF + (size_t)(32 * f + i) * WIDTH + (k - 32)];
   }
   const int ks = frag - BFS_COL, k = 16 * ks + kk;  // colour head
   return i < 3 ? w.p[W_COLOR][(size_t)i * HALF + k] : 0.f;
 }
 
-__device__ __forceinline__ float bf_bias(const Weights24& w, int tile, int i) {
-  if (tile < BFB_PI) return w.p[2 * (tile / 8) + 1][32 * (tile % 8) + i];
-  if (tile < BFB_SIGMA) return w.p[B_PI][32 * (tile - BFB_PI) + i];
+__device__ __forceinline__ float bf_bias(const Weights24& w, const float* __restrict__ fold, int tile, int i) {
+  if (tile < BFB_SIGMA) return w.p[2 * (tile / 8) + 1][32 * (tile % 8) + i];
   if (tile == BFB_SIGMA) return i == 0 ? w.p[B_SIGMA][0] : 0.f;
-  if (tile < BFB_COL) return w.p[B_DIR][32 * (tile - BFB_DIR) + i];
+  if (tile < BFB_COL) return w.p[B_DIR][32 * (tile - BFB_DIR) + i] + fold[32 * (tile - BFB_DIR) + i];  // + W_dir[:, 24:] b_pi
   return i < 3 ? w.p[B_COLOR][i] : 0.f;
 }
 
 // first_thread = BF_NFRAG * 64: only the bias block (the 16x16x32 image shares it and brings its own fragments)
-__global__ __launch_bounds__(256) void k_pack_weights_bf16(const Weights24 w, unsigned char* __restrict__ img, int first_thread) {
+__global__ __launch_bounds__(256) void k_pack_weights_bf16(const Weights24 w, const float* __restrict__ fold, unsigned char* __restrict__ img, int first_thread) {
   const int gid = first_thread + blockIdx.x * 256 + threadIdx.x;
   if (gid < BF_NFRAG * 64) {
     const int frag = gid >> 6, lane = gid & 63, i = lane & 31, h = lane >> 5;
@@ -269,26 +254,26 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16(const Weights24 w, un
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int kk = 4 * h + 2 * (q & 1) + 8 * (q >> 1);
-      v[q] = pack2(bf_weight(w, frag, i, kk, h), bf_weight(w, frag, i, kk + 1, h));
+      v[q] = pack2(bf_weight(w, fold, frag, i, kk, h), bf_weight(w, fold, frag, i, kk + 1, h));
     }
     *reinterpret_cast<u32x4*>(img + BF_BIAS_BYTES + (size_t)frag * BF_FRAG_BYTES + lane * 16) = v;
   } else {
     const int b = gid - BF_NFRAG * 64;
     if (b < BF_BIAS_BYTES / 4) {
       const int tile = b >> 5, i = b & 31;
-      reinterpret_cast<float*>(img)[b] = tile < BF_NBIAS_TILES ? bf_bias(w, tile, i) : 0.f;
+      reinterpret_cast<float*>(img)[b] = tile < BF_NBIAS_TILES ? bf_bias(w, fold, tile, i) : 0.f;
     }
   }
 }
 
-hipError_t launch_pack_weights_bf16(const Weights24& w, unsigned char* img, hipStream_t st) {
+hipError_t launch_pack_weights_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st) {
   const int threads = BF_NFRAG * 64 + BF_BIAS_BYTES / 4;
-  hipLaunchKernelGGL(k_pack_weights_bf16, dim3((threads + 255) / 256), dim3(256), 0, st, w, img, 0);
+  hipLaunchKernelGGL(k_pack_weights_bf16, dim3((threads + 255) / 256), dim3(256), 0, st, w, fold, img, 0);
   return hipGetLastError();
 }
 
-hipError_t launch_pack_bias_block_bf16(const Weights24& w, unsigned char* img, hipStream_t st) {
-  hipLaunchKernelGGL(k_pack_weights_bf16, dim3((BF_BIAS_BYTES / 4 + 255) / 256), dim3(256), 0, st, w, img, BF_NFRAG * 64);
+hipError_t launch_pack_bias_block_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_weights_bf16, dim3((BF_BIAS_BYTES / 4 + 255) / 256), dim3(256), 0, st, w, fold, img, BF_NFRAG * 64);
   return hipGetLastError();
 }
 

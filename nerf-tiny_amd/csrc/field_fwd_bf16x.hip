@@ -27,14 +27,14 @@ constexpr int BXS_L0 = 0;      // 16 tiles x 2
 constexpr int BXS_L1 = 32;     // 16 x 8, likewise L2, L3
 constexpr int BXS_L4 = 416;    // 16 x (8 hidden + 2 gamma_p)
 constexpr int BXS_L5 = 576;    // 16 x 8, likewise L6, L7
-constexpr int BXS_PI = 960;    // 17 x 8: point_info tiles 0..15, tile 16 row 0 = sigma_layer
-constexpr int BXS_DIR = 1096;  // 8 x (1 gamma_d + 8 feat)
-constexpr int BXS_COL = 1168;  // 1 x 4
-constexpr int BX_NFRAG = 1172;
-constexpr int BX_NCHUNK = (BX_NFRAG + BF_CHUNK - 1) / BF_CHUNK;  // 74 (the last chunk is padded)
+constexpr int BXS_SIG = 960;   // 1 x 8: row 0 = sigma_layer (on h7)
+constexpr int BXS_DIR = 968;   // 8 x (1 gamma_d + 8 h7 through W_fold: point_info folded into dir_info, bf16_common.h)
+constexpr int BXS_COL = 1040;  // 1 x 4
+constexpr int BX_NFRAG = 1044;
+constexpr int BX_NCHUNK = (BX_NFRAG + BF_CHUNK - 1) / BF_CHUNK;  // 66 (the last chunk is padded)
 static_assert((size_t)BF_BIAS_BYTES + (size_t)BX_NCHUNK * BF_CHUNK * BF_FRAG_BYTES <= BF_IMAGE_BYTES, "shares the workspace region of the 32x32x16 image");
 // bias block: the float layout of the 32x32x16 image (bf16_common.h), addressed per 16 features
-constexpr int BXB_PI = 32 * BFB_PI, BXB_SIGMA = 32 * BFB_SIGMA, BXB_DIR = 32 * BFB_DIR, BXB_COL = 32 * BFB_COL;
+constexpr int BXB_SIGMA = 32 * BFB_SIGMA, BXB_DIR = 32 * BFB_DIR, BXB_COL = 32 * BFB_COL;
 
 constexpr int BX_LDS_BYTES = BF_LDS_BYTES + BF_WG * 32;  // bias block + ring + 32 bytes per lane of parked encodings = 160 KiB
 static_assert(BX_LDS_BYTES <= 160 * 1024, "LDS of one CU");
@@ -198,32 +198,23 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
   bx_segment<BXS_L4, 16, 8, 2, 4 * 256, 0, 5 * 256>(c, fr, acc, Y, gp, relu_to(X), last_of(relu_to(Y), 15));
   bx_segment<BXS_L5, 16, 8, 0, 5 * 256, 0, 6 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
   bx_segment<BXS_L5 + 128, 16, 8, 0, 6 * 256, 0, 7 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
-  bx_segment<BXS_L5 + 256, 16, 8, 0, 7 * 256, 0, BXB_PI>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
-  // ---- point_info (no activation) + sigma head (tile 16, row 0)  (nerf.py:94, 113-115)
+  bx_segment<BXS_L5 + 256, 16, 8, 0, 7 * 256, 0, BXB_SIGMA>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  // ---- sigma head (one tile, row 0) on h7  (nerf.py:94, 113-115)
   float spre[2] = {0.f, 0.f};
-  auto pi_epi = [&](int f, const Acc2& A) {
-    if (f < 16) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        X[h][f >> 1][2 * (f & 1) + 0] = pack2(A.c[h][0], A.c[h][1]);
-        X[h][f >> 1][2 * (f & 1) + 1] = pack2(A.c[h][2], A.c[h][3]);
-      }
-    } else {
-      spre[0] = A.c[0][0];
-      spre[1] = A.c[1][0];
-    }
+  auto sig_epi = [&](const Acc2& A) {
+    spre[0] = A.c[0][0];
+    spre[1] = A.c[1][0];
   };
-  // the bias of the sigma tile sits at BXB_SIGMA, not behind point_info's 16 tiles: tile 16 is restarted by hand below
-  bx_segment<BXS_PI, 16, 8, 0, BXB_PI, 0, BXB_SIGMA>(c, fr, acc, Y, nullptr, pi_epi, last_of(relu_to(Y), 15));
-  bx_segment<BXS_PI + 128, 1, 8, 0, BXB_SIGMA, 0, BXB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(pi_epi, 15));
-  // ---- dir_info on cat(gamma_d, feat), ReLU (nerf.py:117-118); its first tile also retires the sigma tile
+  bx_segment<BXS_SIG, 1, 8, 0, BXB_SIGMA, 0, BXB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 15));
+  // ---- point_info folded into dir_info: c = relu(W_dir[:, :24] gamma_d + W_fold h7 + bias) (nerf.py:117-118); its first tile also
+  // retires the sigma tile
   {
     const int lane_d = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));  // (re-derived: no address register kept across the stream)
     const u32x4* const back = reinterpret_cast<const u32x4*>(lds + BF_LDS_BYTES) + 2 * (c.wv * 64 + lane_d);
     gd[0][0] = back[0];
     gd[1][0] = back[1];
   }
-  bx_segment<BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, X, relu_to(Y), last_of(pi_epi, 16));
+  bx_segment<BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, Y, relu_to(X), sig_epi);
   // (sample indices are re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing to keep alive or spill)
   const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int n_e = lane_e & 15;
@@ -234,7 +225,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
     if (me < a.M && q0_e) a.sigma[me] = fabsf(spre[h]);
   }
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
-  bx_segment<BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 7));
+  bx_segment<BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X), 7));
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int me = m0 + 16 * h + n_e;
@@ -248,7 +239,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
 // ------------------------------------------------------------------------------------------
 // weight image: fragment (tile T, k-step s), lane (i, q), slot j = W[16T + i][32s + 16 (j >> 2) + 4q + (j & 3)]
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bx_weight(const Weights24& w, int frag, int i, int kk /* input feature inside the k-step */) {
+__device__ __forceinline__ float bx_weight(const Weights24& w, const float* __restrict__ fold, int frag, int i, int kk /* input feature inside the k-step */) {
   if (frag < BXS_L1) {  // L0
     const int T = frag / 2, s = frag % 2, k = 32 * s + kk;
     return k < POINT_DIM ? w.p[0][(size_t)(16 * T + i) * POINT_DIM + k] : 0.f;
@@ -261,19 +252,18 @@ __device__ __forceinline__ float bx_weight(const Weights24& w, int frag, int i, 
     const int x = frag - BXS_L4, T = x / 10, s = x % 10, k = 32 * s + kk;
     return (k < WIDTH + POINT_DIM) ? w.p[8][(size_t)(16 * T + i) * (WIDTH + POINT_DIM) + k] : 0.f;
   }
-  if (frag < BXS_PI) {  // L5..L7
+  if (frag < BXS_SIG) {  // L5..L7
     const int r = frag - BXS_L5, l = 5 + r / 128, x = r % 128, T = x / 8, s = x % 8;
     return w.p[2 * l][(size_t)(16 * T + i) * WIDTH + 32 * s + kk];
   }
-  if (frag < BXS_DIR) {  // point_info, then the sigma tile
-    const int x = frag - BXS_PI, T = x / 8, s = x % 8, k = 32 * s + kk;
-    if (T < 16) return w.p[W_PI][(size_t)(16 * T + i) * WIDTH + k];
+  if (frag < BXS_DIR) {  // the sigma tile on h7
+    const int s = frag - BXS_SIG, k = 32 * s + kk;
     return i == 0 ? w.p[W_SIGMA][k] : 0.f;
   }
-  if (frag < BXS_COL) {  // dir_info: [128][280] = cat(gamma_d (24), feat)
+  if (frag < BXS_COL) {  // dir_info: gamma_d columns of W_dir (24 -> 32), then W_fold = W_dir[:, 24:] W_pi on h7
     const int x = frag - BXS_DIR, T = x / 9, s = x % 9;
     if (s == 0) return kk < DIR_DIM ? w.p[W_DIR][(size_t)(16 * T + i) * (WIDTH + DIR_DIM) + kk] : 0.f;
-    return w.p[W_DIR][(size_t)(16 * T + i) * (WIDTH + DIR_DIM) + DIR_DIM + 32 * (s - 1) + kk];
+    return fold[HALF + (size_t)(16 * T + i) * WIDTH + 32 * (s - 1) + kk];
   }
   if (frag < BX_NFRAG) {  // colour head
     const int s = frag - BXS_COL, k = 32 * s + kk;
@@ -283,7 +273,7 @@ __device__ __forceinline__ float bx_weight(const Weights24& w, int frag, int i, 
 }
 
 // the bias block is the 32x32x16 image's (same float layout); only the fragments differ
-__global__ __launch_bounds__(256) void k_pack_weights_bf16x(const Weights24 w, unsigned char* __restrict__ img) {
+__global__ __launch_bounds__(256) void k_pack_weights_bf16x(const Weights24 w, const float* __restrict__ fold, unsigned char* __restrict__ img) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= BX_NCHUNK * BF_CHUNK * 64) return;
   const int frag = gid >> 6, lane = gid & 63, i = lane & 15, q = lane >> 4;
@@ -291,16 +281,16 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16x(const Weights24 w, u
 #pragma unroll
   for (int e = 0; e < 4; ++e) {  // slots 2e, 2e + 1
     const int kk = 16 * (e >> 1) + 4 * q + 2 * (e & 1);
-    v[e] = pack2(bx_weight(w, frag, i, kk), bx_weight(w, frag, i, kk + 1));
+    v[e] = pack2(bx_weight(w, fold, frag, i, kk), bx_weight(w, fold, frag, i, kk + 1));
   }
   *reinterpret_cast<u32x4*>(img + BF_BIAS_BYTES + (size_t)frag * BF_FRAG_BYTES + lane * 16) = v;
 }
 
-hipError_t launch_pack_weights_bf16x(const Weights24& w, unsigned char* img, hipStream_t st) {
-  hipError_t e = launch_pack_bias_block_bf16(w, img, st);
+hipError_t launch_pack_weights_bf16x(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st) {
+  hipError_t e = launch_pack_bias_block_bf16(w, fold, img, st);
   if (e != hipSuccess) return e;
   const int threads = BX_NCHUNK * BF_CHUNK * 64;
-  hipLaunchKernelGGL(k_pack_weights_bf16x, dim3((threads + 255) / 256), dim3(256), 0, st, w, img);
+  hipLaunchKernelGGL(k_pack_weights_bf16x, dim3((threads + 255) / 256), dim3(256), 0, st, w, fold, img);
   return hipGetLastError();
 }
 

@@ -105,13 +105,15 @@ struct MergeArgs {
 };
 
 hipError_t launch_pack_weights(const Weights24& w, float* b_fold, float4* out, int nseg, hipStream_t st);  // b_fold: HALF floats (common.h SEG_FOLD)
+hipError_t launch_fold_weights(const Weights24& w, float* fold, hipStream_t st);  // fold: FOLD_FLOATS (b_fold, then W_fold): bf16-MLP variant
 hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st);
-hipError_t launch_pack_weights_bf16(const Weights24& w, unsigned char* img, hipStream_t st);
-hipError_t launch_pack_bias_block_bf16(const Weights24& w, unsigned char* img, hipStream_t st);
+// the bf16 packers read the fp32 fold (launch_fold_weights, same stream, before them)
+hipError_t launch_pack_weights_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
+hipError_t launch_pack_bias_block_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st);  // inference, 16x16x32 MFMA form
-hipError_t launch_pack_weights_bf16x(const Weights24& w, unsigned char* img, hipStream_t st);
+hipError_t launch_pack_weights_bf16x(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
 hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st);
 size_t merge_lds_bytes(int P);
@@ -234,7 +236,7 @@ struct SmallGradArgs {
 hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st);
 hipError_t launch_field_bwd_reg(const FieldBwdArgs& a, bool fine, hipStream_t st);
 hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st);
-hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, unsigned char* img, hipStream_t st);
+hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 size_t dw_bf16_slab_floats();
 hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned char* X1, int x1_ks, const unsigned char* X2, int x2_ks,
                                const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st);

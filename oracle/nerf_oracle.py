@@ -175,7 +175,11 @@ def mlp_bf16(params, gp: torch.Tensor, gd: torch.Tensor, return_hidden: bool = F
     """NOT a restatement of the reference (which has no reduced precision): the arithmetic the build's bf16-MLP variant
     (BASELINE.json cfg3, flag NERF_HIP_BF16_MLP) is specified to perform, emulated in fp32 -- same graph as ``mlp``
     (nerf.py:101-124) with every linear layer's weights AND inputs rounded to bf16 (RNE), fp32 products/accumulation,
-    fp32 biases and fp32 activations.  Used only to check that variant (tests/test_gpu_bf16.py)."""
+    fp32 biases and fp32 activations.  One algebraic step is taken BEFORE rounding: point_info has no activation
+    (nerf.py:117), so point_info and the feature columns of dir_info are one linear map of h7; the variant forms
+    W_fold = W_dir[:, 24:] @ W_pi and b_fold = W_dir[:, 24:] @ b_pi + b_dir in fp32 and rounds W_fold to bf16 ONCE (the
+    intermediate ``feat`` is never rounded -- closer to the fp32 network than rounding both factors and feat).
+    Used only to check that variant (tests/test_gpu_bf16.py)."""
     W = lambda n: _bf16(params[n])
     b = lambda n: params[n]
     gp, gd = _bf16(gp), _bf16(gd)
@@ -186,8 +190,12 @@ def mlp_bf16(params, gp: torch.Tensor, gd: torch.Tensor, return_hidden: bool = F
         h = _bf16(torch.relu(F.linear(inp, W(f"network.point_layer.{i}.0.weight"), b(f"network.point_layer.{i}.0.bias"))))
         hidden.append(h)
     sigma = torch.abs(F.linear(h, W("network.sigma_layer.0.weight"), b("network.sigma_layer.0.bias")))
-    feat = _bf16(F.linear(h, W("network.point_info.weight"), b("network.point_info.bias")))
-    c = _bf16(torch.relu(F.linear(torch.cat((gd, feat), dim=-1), W("network.dir_info.0.weight"), b("network.dir_info.0.bias"))))
+    Wd, Wp = params["network.dir_info.0.weight"], params["network.point_info.weight"]
+    n_d = gd.shape[-1]
+    W_fold = _bf16(Wd[:, n_d:] @ Wp)
+    b_fold = Wd[:, n_d:] @ b("network.point_info.bias") + b("network.dir_info.0.bias")
+    feat = F.linear(h, W("network.point_info.weight"), b("network.point_info.bias"))  # (not part of the folded graph; returned for inspection)
+    c = _bf16(torch.relu(F.linear(gd, _bf16(Wd[:, :n_d])) + F.linear(h, W_fold) + b_fold))
     rgb = torch.sigmoid(F.linear(c, W("network.color_layer.0.weight"), b("network.color_layer.0.bias")))
     if return_hidden:
         return rgb, sigma.squeeze(-1), hidden, feat, c

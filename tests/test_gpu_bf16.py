@@ -74,8 +74,8 @@ def test_forward_bf16(oracle, pkg, dev, name):
 # ---------------------------------------------------------------------------------------------------------------
 # training (forward with saving + backward chain + weight-gradient GEMMs, all on bf16 MFMA)
 # ---------------------------------------------------------------------------------------------------------------
-BS_KS = [4] + [16] * 8 + [16, 8, 2]     # bf16_common.h: gamma_p, h0..h7, feat, c, gamma_d
-BG_KS = [16] * 8 + [16, 8, 2]           # dpre0..7, dfeat, dpre_dir, (dz, dspre)
+BS_KS = [4] + [16] * 8 + [8, 2]         # bf16_common.h: gamma_p, h0..h7, c, gamma_d (point_info is folded into dir_info: no feat)
+BG_KS = [16] * 8 + [8, 2]               # dpre0..7, dpre_dir, (dz, dspre)
 
 
 def _wave_blocks(B, N):
@@ -131,7 +131,7 @@ def test_bf16_saved_activations_and_gradients_coarse_only(oracle, pkg, dev, name
     with torch.no_grad():
         _, _, hidden, feat, cc = oracle.mlp_bf16(params, oracle.encode(st["pts_c"], f_p), st["gd"][:, None, :].expand(-1, Nc, -1), return_hidden=True)
     M = B * Nc
-    for tensor, ref in [(1 + l, hidden[l]) for l in (0, 3, 7)] + [(9, feat), (10, cc)]:
+    for tensor, ref in [(1 + l, hidden[l]) for l in (0, 3, 7)] + [(9, cc)]:
         got = _decode(bsave, wb_tot, BS_KS, tensor, 0, wb_c)[:M]
         ref = ref.reshape(M, -1)
         d = (got[:, :ref.shape[1]] - ref).abs()
