@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 1_182_976  # GEMM MACs x 2 of one MLP evaluation
+EXEC_FLOP_PER_SAMPLE = FLOP_PER_SAMPLE - 2 * 256 * 256  # executed: point_info (256 x 256) folded into dir_info's feature columns
 B, NC, NF = 4096, 64, 128
 FLOP_PER_RAY_FWD = FLOP_PER_SAMPLE * (NC + NF)  # 227,131,392
 FLOP_PER_RAY_TRAIN = 676_282_368
@@ -201,12 +202,16 @@ def cpu_baseline(seconds_budget=12.0):
     return out
 
 
-def read_traffic(kernel_keys, train=False, scale=None):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summaries (scripts/profile_pmc.sh + scripts/summarize_pmc.py:
+PMC_FILES = {(False, False): "pmc_latest.json", (True, False): "pmc_train_latest.json", (False, True): "pmc_bf16_fwd_latest.json",
+             (True, True): "pmc_bf16_train_latest.json"}  # (train, bf16) -> committed summary under profiles/
+
+
+def read_traffic(leg, kernel_keys, scale=None):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summaries (scripts/collect_profiles_r03.sh + scripts/summarize_pmc.py:
     separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction): the mean over `kernel_keys`
     (per-kernel averages over their launches), or with `scale` = {key: launches per step} their sum per step.
     Not measured in this run: the block says so in `traffic_source`."""
-    p = os.path.join(ROOT, "profiles", "pmc_train_latest.json" if train else "pmc_latest.json")
+    p = os.path.join(ROOT, "profiles", PMC_FILES[(leg.train, leg.bf16)])
     try:
         with open(p) as f:
             d = json.load(f)
@@ -286,58 +291,67 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
 def rooflines(leg, prof, b_local, steps):
     """Roofline blocks of one leg from the library's HIP events (recorded on the stream the kernels run on)."""
     peak = PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS
+    src = "profiles/" + PMC_FILES[(leg.train, leg.bf16)] + " (committed rocprofv3 --pmc passes of this leg; not re-measured in this run)"
 
-    def mfma(kernel, keys, flop_per_launch, traffic_key=None):
+    def mfma(kernel, keys, flop_per_launch, traffic_keys):
         ms = sum(prof.get(k, (0.0, 0))[0] for k in keys)
         n = sum(prof.get(k, (0.0, 0))[1] for k in keys)
         avg = ms / max(n, 1)
         ach = flop_per_launch / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
-        blk = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-               "traffic": read_traffic(traffic_key, train=leg.train) if traffic_key else None, "kernel": kernel, "avg_launch_ms": round(avg, 4),
-               "launches": n, "flop_per_launch": flop_per_launch}
-        if traffic_key:
-            blk["traffic_source"] = ("profiles/pmc_train_latest.json" if leg.train else "profiles/pmc_latest.json") + \
-                " (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
-        return blk
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": read_traffic(leg, traffic_keys), "traffic_source": src, "kernel": kernel, "avg_launch_ms": round(avg, 4),
+                "launches": n, "flop_per_launch": flop_per_launch}
 
     # dominant forward kernel: launched twice per step (coarse pass B*Nc samples, fine pass B*Nf samples); "launch" = the
-    # average launch, so that rocprofv3's per-kernel average is directly comparable
+    # average launch, so that rocprofv3's per-kernel average is directly comparable.  `achieved` counts the ALGORITHMIC FLOPs of the
+    # reference's network (SURVEY.md 8d: 1,182,976 per sample); the kernels EXECUTE 8/9 of them: point_info is folded into dir_info
+    # (one 128 x 256 layer instead of 256 x 256 + 128 x 256, DESIGN.md section 3) -- `executed_flop_frac` says so.
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
+    fwd_key = (["k_field_fwd_bf16<true>"] if leg.train else ["k_field_fwd_bf16x"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
     fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
-               FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, None if leg.bf16 else ["k_field_fwd"])
+               FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key)
+    fwd["executed_flop_frac"] = round(EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE, 4)
     if not leg.train:
         return fwd, None
-    chain = mfma(("k_field_bwd_bf16" if leg.bf16 else "k_field_bwd_reg") + " (dX chain; average of the fine- and coarse-pass launches)",
+    sfx = "bf16" if leg.bf16 else "reg"
+    chain = mfma(f"k_field_bwd_{sfx} (dX chain; average of the fine- and coarse-pass launches)",
                  ("bwd_field_fine", "bwd_field_coarse"), (CHAIN_FLOP_COARSE * b_local * NC + CHAIN_FLOP_FINE * b_local * NF) // 2,
-                 None if leg.bf16 else ["k_field_bwd_reg<true>", "k_field_bwd_reg<false>"])
+                 [f"k_field_bwd_{sfx}<true>", f"k_field_bwd_{sfx}<false>"])
     # weight-gradient phase: all dW = G^T X products of one step (same MACs as one forward over all samples) + slab reduces + thin heads
     dw_ms = prof.get("bwd_dw", (0.0, 0))[0] / max(prof.get("bwd_dw", (0.0, 1))[1], 1)
+    launches = DW_BF16_LAUNCHES if leg.bf16 else DW_LAUNCHES
+    dw_traffic = read_traffic(leg, list(launches), scale=launches)
+    dw_src = src + "; per step: " + ", ".join(f"{n} x {k}" for k, n in launches.items())
     if leg.bf16:
         # HBM-bound by construction (DESIGN.md section 7): bytes of bf16 operands per 32-sample wave block, read once each
         wb = ((b_local * NC + 255) // 256 + (b_local * NF + 255) // 256) * 8
         dw_bytes = DW_BF16_KIB_PER_WAVE_BLOCK * 1024 * wb
         dw = {"bound": "hbm", "achieved": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-              "frac": round(dw_bytes / (dw_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4), "traffic": None,
+              "frac": round(dw_bytes / (dw_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4), "traffic": dw_traffic, "traffic_source": dw_src,
               "kernel": "k_dw_bf16 (the weight-gradient passes + slab reduces of one step)", "avg_launch_ms": round(dw_ms, 4),
               "launches": prof.get("bwd_dw", (0.0, 0))[1], "bytes_per_launch": dw_bytes}
     else:
         flop = FLOP_PER_SAMPLE * b_local * (NC + NF)
         ach = flop / (dw_ms * 1e-3) / 1e12 if dw_ms > 0 else 0.0
         dw = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-              "traffic": read_traffic(list(DW_LAUNCHES), train=True, scale=DW_LAUNCHES),
-              "traffic_source": "profiles/pmc_train_latest.json (committed rocprofv3 --pmc passes; per step: " + ", ".join(f"{n} x {k}" for k, n in DW_LAUNCHES.items()) + ")",
-              "kernel": "k_dw4 / k_dw_thin / k_dw_reduce / k_dir_* (all weight-gradient products of one step incl. the reduce and the thin colour head = one 'launch')",
+              "traffic": dw_traffic, "traffic_source": dw_src,
+              "kernel": "k_dw4 / k_dw_thin / k_dw_reduce / k_fold_grads / k_dir_* (all weight-gradient products of one step incl. the reduce and the thin colour head = one 'launch')",
               "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "flop_per_launch": flop}
     phases = {"forward_with_saves": fwd, "dx_chain": chain, "dw": dw}
     dominant = max(phases.values(), key=lambda b: b["avg_launch_ms"] * (2 if b is not dw else 1))
     return dominant, phases
 
 
-# launches of the fp32 weight-gradient phase per train step (dw_f32.hip, field_bwd.hip): the 128 x 128-block products (layers 1-7,
-# point_info + sigma head, dir_info), the 128 x 64-block ones (layer 0, layer 4's skip columns), the colour head, the reduce, and the
-# three small kernels of dir_info's direction-encoding columns (their per-ray sums come out of the dir_info product)
-DW_LAUNCHES = {"k_dw4<4>": 9, "k_dw4<2>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_dir_prep": 1, "k_dir_gamma_part": 1, "k_dir_gamma_final": 1}
-DW_BF16_KIB_PER_WAVE_BLOCK = 318  # G and X pieces of bf16_common.h over the 11 products (DESIGN.md section 7)
+# launches of the fp32 weight-gradient phase per train step (dw_f32.hip): the 128 x 128-block products (layers 1-7), the folded
+# dpre_dir^T h7 product that carries the sigma head (k_dw4<4, true>), the 128 x 64-block ones (layer 0, layer 4's skip columns), the
+# colour head, the reduce, the fold's gradient kernel and the three small kernels of dir_info's direction-encoding columns
+DW_LAUNCHES = {"k_dw4<4, false>": 7, "k_dw4<4, true>": 1, "k_dw4<2, false>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_fold_grads": 1,
+               "k_dir_prep": 1, "k_dir_gamma_part": 1, "k_dir_gamma_final": 1}
+# bf16-MLP variant (dw_bf16.hip): layer 0, the six 256 x 256 products in one launch, layer 4, the folded product with the sigma head,
+# the colour head, their reduces, the fold's gradient kernel
+DW_BF16_LAUNCHES = {"k_dw_bf16<2, false>": 1, "k_dw_bf16<8, false>": 1, "k_dw_bf16<10, false>": 1, "k_dw_bf16<9, true>": 1,
+                    "k_dw_bf16<4, false>": 1, "k_dw_bf16_reduce": 13, "k_fold_grads": 1}
+DW_BF16_KIB_PER_WAVE_BLOCK = 280  # G and X pieces of bf16_common.h over the products (142 + 138 KiB; DESIGN.md section 7)
 
 
 def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong):

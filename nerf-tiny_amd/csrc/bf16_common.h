@@ -43,10 +43,10 @@ constexpr size_t BF_IMAGE_BYTES = (size_t)BF_BIAS_BYTES + (size_t)BF_NFRAG * BF_
 //  COLT  4 tiles x 4 k-steps (only k-step 0, inputs 0..2 = dz, are non-zero)       d c    = W_color^T dz
 //  FOLDT 8 x 9: 8 k-steps W_fold^T dpre_dir + 1 k-step w_sigma (input slot 3 = dspre)   d h7
 //  L7T, L6T, L5T, L4T (hidden columns), L3T, L2T, L1T: 8 x 16 each
-//  fine pass only, d gamma_p:  G0T 2 x 16 = W_0^T (input dpre0),  G4T 2 x 16 = W_4[:, 256:]^T (input dpre4, re-read)
+//  fine pass only, d gamma_p:  2 tiles x (16 k-steps of W_0^T (input dpre0) + 16 k-steps of W_4[:, 256:]^T (input dpre4, re-read))
 // One image serves both passes: the coarse pass stops after L1T.
 constexpr int BBS_COLT = 0, BBS_FOLDT = 16, BBS_L7T = 88, BBS_L4T = 472, BBS_L3T = 600;
-constexpr int BBS_G0T = 984, BBS_G4T = 1016;
+constexpr int BBS_G0T = 984;
 constexpr int BBC_NFRAG = 984, BBF_NFRAG = 1048;
 constexpr int BBC_NCHUNK = (BBC_NFRAG + BF_CHUNK - 1) / BF_CHUNK, BBF_NCHUNK = (BBF_NFRAG + BF_CHUNK - 1) / BF_CHUNK;
 constexpr size_t BB_IMAGE_BYTES = (size_t)BF_BIAS_BYTES + (size_t)BBF_NCHUNK * BF_CHUNK * BF_FRAG_BYTES;

@@ -65,7 +65,11 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
   const int m = blockIdx.x * (BF_WG / 2) + c.wv * 32 + j;
   const bool valid = m < a.M;
   const int mc = valid ? m : a.M - 1;
+#ifdef NERF_TIMING_SAVE_ALIAS  // (timing experiments only: masks read from / gradients written to the same few KiB)
+  const int wb = c.wv;
+#else
   const int wb = a.wb0 + blockIdx.x * (BF_WG / 64) + c.wv;
+#endif
 
   // ---- ordinary loads first: upstream gradients -> dz (colour head, pre-sigmoid) and dspre (sigma head, pre-abs)
   float dz[3];
@@ -134,32 +138,32 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
   auto nothing = [](const f32x16&) {};
 
   // colour head: dc = W_color^T dz, through c's ReLU -> dpre_dir
-  bf_segment<S, BBS_COLT, 4, 4, 0, -1, 0, -1>(c, fr, acc, zin, nullptr, grad_to(Y, BG_D, 8, 4), nothing);
+  bf_segment<S, BBS_COLT, 4, 4, 0, -1, 0, -1>(c, fr, acc, zin, nullptr, grad_to(X, BG_D, 8, 4), nothing);
   // dir_info and point_info as ONE transposed layer (point_info has no activation: folded, bf16_common.h) + the sigma head:
   // dh7 = W_fold^T dpre_dir + w_sigma dspre, through h7's ReLU
-  bf_segment<S, BBS_FOLDT, 8, 8, 1, -1, 0, -1>(c, fr, acc, Y, zin, grad_to(X, BG_L0 + 7, 7), last_of(grad_to(Y, BG_D, 8, 4), 3));
-  bf_segment<S, BBS_L7T, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 6, 6), last_of(grad_to(X, BG_L0 + 7, 7), 7));
-  bf_segment<S, BBS_L7T + 128, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 5, 5), last_of(grad_to(Y, BG_L0 + 6, 6), 7));
-  bf_segment<S, BBS_L7T + 256, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 4, 4), last_of(grad_to(X, BG_L0 + 5, 5), 7));
-  bf_segment<S, BBS_L4T, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 3, 3), last_of(grad_to(Y, BG_L0 + 4, 4), 7));
-  bf_segment<S, BBS_L3T, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 2, 2), last_of(grad_to(X, BG_L0 + 3, 3), 7));
-  bf_segment<S, BBS_L3T + 128, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 1, 1), last_of(grad_to(Y, BG_L0 + 2, 2), 7));
-  bf_segment<S, BBS_L3T + 256, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 0, 0), last_of(grad_to(X, BG_L0 + 1, 1), 7));
+  bf_segment<S, BBS_FOLDT, 8, 8, 1, -1, 0, -1>(c, fr, acc, X, zin, grad_to(Y, BG_L0 + 7, 7), last_of(grad_to(X, BG_D, 8, 4), 3));
+  bf_segment<S, BBS_L7T, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 6, 6), last_of(grad_to(Y, BG_L0 + 7, 7), 7));
+  bf_segment<S, BBS_L7T + 128, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 5, 5), last_of(grad_to(X, BG_L0 + 6, 6), 7));
+  bf_segment<S, BBS_L7T + 256, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 4, 4), last_of(grad_to(Y, BG_L0 + 5, 5), 7));
+  bf_segment<S, BBS_L4T, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 3, 3), last_of(grad_to(X, BG_L0 + 4, 4), 7));
+  bf_segment<S, BBS_L3T, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 2, 2), last_of(grad_to(Y, BG_L0 + 3, 3), 7));
+  bf_segment<S, BBS_L3T + 128, 8, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, grad_to(Y, BG_L0 + 1, 1), last_of(grad_to(X, BG_L0 + 2, 2), 7));
+  bf_segment<S, BBS_L3T + 256, 8, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, grad_to(X, BG_L0 + 0, 0), last_of(grad_to(Y, BG_L0 + 1, 1), 7));
   if constexpr (!FINE) {
-    grad_to(Y, BG_L0 + 0, 0)(7, acc[1]);  // the last tile of the stream
+    grad_to(X, BG_L0 + 0, 0)(7, acc[1]);  // the last tile of the stream
   } else {
     // ---- d gamma_p (fp32) = W_0^T dpre0 + W_4[:, 256:]^T dpre4  (nerf.py:104, 109).  dpre4 is long gone from the
     // registers: the wave reads back the 16 pieces it stored itself ~500 MFMAs ago (complete: every counted wait since
     // has retired them; nobody on this CU has read those lines, so no stale copy can be hit), while G0T runs.
+    // One segment: tile f of d gamma_p runs over the 16 k-steps of dpre0 (X, W_0^T) and then the 16 k-steps of dpre4 (Y, W_4[:, 256:]^T)
+    // in the same accumulator (the weight image interleaves the two matrices per tile): no second accumulator pair to add up.
     f32x16 dgp[2];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-      X[ks] = *reinterpret_cast<const u32x4*>(gvl + ((size_t)a.wb_tot * bg_cum(BG_L0 + 4) + (size_t)wb * 16 + ks) * BF_FRAG_BYTES);
-    bf_segment<S, BBS_G0T, 2, 16, 0, -1, 0, -1>(c, fr, acc, Y, nullptr, [&](int f, const f32x16& A) { dgp[f] = A; },
-                                                last_of(grad_to(Y, BG_L0 + 0, 0), 7));
-    bf_segment<S, BBS_G4T, 2, 16, 0, -1, 0, -1>(c, fr, acc, X, nullptr, [&](int f, const f32x16& A) { dgp[f] += A; },
-                                                [&](const f32x16& A) { dgp[1] = A; });
-    dgp[1] += acc[1];
+      Y[ks] = *reinterpret_cast<const u32x4*>(gvl + ((size_t)a.wb_tot * bg_cum(BG_L0 + 4) + (size_t)wb * 16 + ks) * BF_FRAG_BYTES);
+    bf_segment<S, BBS_G0T, 2, 16, 16, -1, 0, -1>(c, fr, acc, X, Y, [&](int, const f32x16& A) { dgp[0] = A; },
+                                                 last_of(grad_to(X, BG_L0 + 0, 0), 7));
+    dgp[1] = acc[1];
     // gamma -> point -> depth (t_fine is not detached, quirk Q9).  dgp[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of
     // pair pi = 16t + 4g + 2h + e
     int mcl = mc;
@@ -212,13 +216,11 @@ __device__ __forceinline__ float bb_weight(const Weights24& w, const float* __re
     const int ld = (l == 4) ? WIDTH + POINT_DIM : WIDTH;
     return w.p[2 * l][(size_t)(16 * ks + kk) * ld + 32 * f + i];
   }
-  if (frag < BBS_G4T) {  // G0T
-    const int q = frag - BBS_G0T, f = q / 16, ks = q % 16, col = 32 * f + i;
-    return col < POINT_DIM ? w.p[0][(size_t)(16 * ks + kk) * POINT_DIM + col] : 0.f;
-  }
-  if (frag < BBF_NFRAG) {  // G4T: skip columns
-    const int q = frag - BBS_G4T, f = q / 16, ks = q % 16, col = 32 * f + i;
-    return col < POINT_DIM ? w.p[8][(size_t)(16 * ks + kk) * (WIDTH + POINT_DIM) + WIDTH + col] : 0.f;
+  if (frag < BBF_NFRAG) {  // d gamma_p, fine pass: tile f = 16 k-steps of W_0^T (input dpre0), then 16 k-steps of W_4[:, 256:]^T (input dpre4)
+    const int q = frag - BBS_G0T, f = q / 32, ks = q % 32, col = 32 * f + i;
+    if (col >= POINT_DIM) return 0.f;
+    if (ks < 16) return w.p[0][(size_t)(16 * ks + kk) * POINT_DIM + col];
+    return w.p[8][(size_t)(16 * (ks - 16) + kk) * (WIDTH + POINT_DIM) + WIDTH + col];
   }
   return 0.f;  // padding up to whole chunks
 }

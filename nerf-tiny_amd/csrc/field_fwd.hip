@@ -45,6 +45,8 @@ __device__ __forceinline__ PackDesc pack_desc(int s) {
     case SEG_L7: return {14, 256, 0, 256, 256, 0};
     case SEG_PI: return {W_PI, 256, 0, 256, 256, 0};
     case SEG_DIR: return {W_DIR, 280, 24, 128, 256, 0};
+    case SEG_FOLD: return {24, 256, 0, 128, 256, 0};
+    case SEG_T_FOLD: return {24, 256, 0, 256, 128, 1};
     // transposed: rows = number of output features of the transposed product (= inputs of the layer),
     // cols = reduction length (= outputs of the layer)
     case SEG_T_DIR: return {W_DIR, 280, 24, 256, 128, 1};
@@ -70,9 +72,8 @@ constexpr SegOffTable make_seg_off_table() {
 }
 __constant__ const SegOffTable kSegOff = make_seg_off_table();
 
-// One element of the folded matrix W_fold[o][k] = sum_j W_dir[o][24 + j] * W_pi[j][k] (common.h SEG_FOLD): an fp32 fma chain over
-// j = 0 .. 255 in ascending order, so that the forward segment, the transposed segment and the weight-gradient kernels all see the
-// SAME fp32 matrix bit for bit.
+// Four elements of the folded matrix W_fold[o][k] = sum_j W_dir[o][24 + j] * W_pi[j][k] (common.h SEG_FOLD): fp32 fma chains over
+// j = 0 .. 255 in ascending order.
 __device__ __forceinline__ float4 fold4_k(const float* __restrict__ wdir, const float* __restrict__ wpi, int o, int k0) {  // W_fold[o][k0 .. k0+3]
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* dr = wdir + (size_t)o * (WIDTH + DIR_DIM) + DIR_DIM;
@@ -88,23 +89,8 @@ __device__ __forceinline__ float4 fold4_k(const float* __restrict__ wdir, const 
   }
   return acc;
 }
-__device__ __forceinline__ float4 fold4_o(const float* __restrict__ wdir, const float* __restrict__ wpi, int o0, int k) {  // W_fold[o0 .. o0+3][k]
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* dr = wdir + (size_t)o0 * (WIDTH + DIR_DIM) + DIR_DIM;
-  const float* pc = wpi + k;
-#pragma unroll 8
-  for (int j = 0; j < WIDTH; ++j) {
-    const float q = pc[(size_t)j * WIDTH];
-    acc.x = __builtin_fmaf(dr[j], q, acc.x);
-    acc.y = __builtin_fmaf(dr[(WIDTH + DIR_DIM) + j], q, acc.y);
-    acc.z = __builtin_fmaf(dr[2 * (WIDTH + DIR_DIM) + j], q, acc.z);
-    acc.w = __builtin_fmaf(dr[3 * (WIDTH + DIR_DIM) + j], q, acc.w);
-  }
-  return acc;
-}
-
-// The fold as a kernel of its own, for the bf16-MLP variant (its packers round W_fold to bf16): fold[0 .. 128) = b_fold,
-// fold[128 + o * 256 + k] = W_fold[o][k].  33 blocks: block b < 32 = rows 4b .. 4b+3 (one row per wave: the W_dir element of a step is
+// The fold, in front of every packer (fp32 and bf16-MLP variant alike): fold[0 .. 128) = b_fold = W_dir[:, 24:] b_pi (k_rays adds it to
+// every ray's dir_info start vector), fold[128 + o * 256 + k] = W_fold[o][k].  33 blocks: block b < 32 = rows 4b .. 4b+3 (one row per wave: the W_dir element of a step is
 // wave-uniform, the W_pi row a coalesced KiB), block 32 = b_fold.
 __global__ __launch_bounds__(256) void k_fold_weights(Weights24 w, float* __restrict__ fold) {
   if (blockIdx.x == 32) {
@@ -128,22 +114,12 @@ hipError_t launch_fold_weights(const Weights24& w, float* fold, hipStream_t st) 
   return hipGetLastError();
 }
 
-// b_fold (HALF floats behind the packed image's caller-provided pointer): W_dir[:, 24:] b_pi -- what point_info's bias contributes to
-// dir_info's pre-activation; k_rays adds it to every ray's start vector (dvec).
-__global__ __launch_bounds__(256) void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg, float* __restrict__ b_fold) {
+// The folded segments (SEG_FOLD, SEG_T_FOLD) are packed from the fp32 W_fold that k_fold_weights left in the workspace (launched in
+// front of this kernel on the same stream): forward, transposed and -- in the bf16 variant -- rounded images all come from ONE matrix.
+__global__ __launch_bounds__(256) void k_pack_weights(Weights24 w, float4* __restrict__ out, int nseg, const float* __restrict__ fold) {
   // one thread per float4 of the packed image
   const int total = kSegOff.v[nseg];
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total + HALF; idx += gridDim.x * blockDim.x) {
-    if (idx >= total) {  // the HALF extra threads: b_fold
-      const int o = idx - total;
-      const float* dr = w.p[W_DIR] + (size_t)o * (WIDTH + DIR_DIM) + DIR_DIM;
-      const float* bp = w.p[B_PI];
-      float s = 0.f;
-#pragma unroll 8
-      for (int j = 0; j < WIDTH; ++j) s = __builtin_fmaf(dr[j], bp[j], s);
-      if (b_fold) b_fold[o] = s;
-      continue;
-    }
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     int s = 0;
 #pragma unroll 1
     while (s + 1 < nseg && idx >= kSegOff.v[s + 1]) ++s;
@@ -154,10 +130,8 @@ __global__ __launch_bounds__(256) void k_pack_weights(Weights24 w, float4* __res
     const int ft = (local >> 6) / kbn;
     const int f = ft * 32 + (lane & 31);
     const int k0 = kb * 8 + 4 * (lane >> 5);
-    if (s == SEG_FOLD) { out[idx] = fold4_k(w.p[W_DIR], w.p[W_PI], f, k0); continue; }    // feature = dir_info row, k = h7 index
-    if (s == SEG_T_FOLD) { out[idx] = fold4_o(w.p[W_DIR], w.p[W_PI], k0, f); continue; }  // feature = h7 index, k = dir_info row
     const PackDesc d = pack_desc(s);
-    const float* W = w.p[d.src];
+    const float* W = d.src < 24 ? w.p[d.src] : fold + HALF;  // src 24: W_fold[128][256]
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!d.transposed) {
       // four consecutive inputs of one output row: one 16-byte load (every row length and column offset is a multiple of 4 floats,
@@ -448,9 +422,10 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldArgs a) {
 // ------------------------------------------------------------------------------------------
 // launchers (called from api.cpp)
 // ------------------------------------------------------------------------------------------
-hipError_t launch_pack_weights(const Weights24& w, float* b_fold, float4* out, int nseg, hipStream_t st) {
-  const int total = seg_off4(nseg) + HALF;
-  hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, st, w, out, nseg, b_fold);
+hipError_t launch_pack_weights(const Weights24& w, float* fold, float4* out, int nseg, hipStream_t st) {
+  if (hipError_t e = launch_fold_weights(w, fold, st)) return e;
+  const int total = seg_off4(nseg);
+  hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, st, w, out, nseg, fold);
   return hipGetLastError();
 }
 

@@ -120,7 +120,11 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
 
   // ---- training: this wave's block of the fragment-layout save buffers (bf16_common.h); every lane stores, also
   // lanes beyond the pass (they hold a copy of the last sample): the counted waits rely on the stores being issued
+#ifdef NERF_TIMING_SAVE_ALIAS  // (timing experiments only: every save lands in the same few KiB -> the stores issue, HBM sees none)
+  const int wb = c.wv;
+#else
   const int wb = a.wb0 + blockIdx.x * (BF_WG / 64) + c.wv;
+#endif
   unsigned char* const svl = SAVE ? a.bsave + lane * 16 : nullptr;
   unsigned char* const mkl = SAVE ? reinterpret_cast<unsigned char*>(a.bmask) + lane * 16 : nullptr;
   unsigned mw[4] = {0u, 0u, 0u, 0u};

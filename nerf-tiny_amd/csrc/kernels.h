@@ -104,7 +104,7 @@ struct MergeArgs {
   float* C_fine;   // [B][3]
 };
 
-hipError_t launch_pack_weights(const Weights24& w, float* b_fold, float4* out, int nseg, hipStream_t st);  // b_fold: HALF floats (common.h SEG_FOLD)
+hipError_t launch_pack_weights(const Weights24& w, float* fold, float4* out, int nseg, hipStream_t st);  // fold: FOLD_FLOATS scratch (launch_fold_weights runs first)
 hipError_t launch_fold_weights(const Weights24& w, float* fold, hipStream_t st);  // fold: FOLD_FLOATS (b_fold, then W_fold): bf16-MLP variant
 hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);

@@ -22,16 +22,17 @@ for k, cs in acc.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]:
         d["mfma_busy_over_sq_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CYCLES"]
     key = k
-    if "k_field_fwd" in k and "bf16" not in k:  # the dominant kernel of bench.py, whichever fp32 instantiation ran
+    if "k_field_fwd" in k and "bf16" not in k and "<true" not in k:  # the dominant kernel of bench.py's headline leg (inference instantiation)
         key = "k_field_fwd"
     out[key] = d
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 p = os.path.join(root, "profiles", f"{tag}_{mode}_pmc.json")
 json.dump(out, open(p, "w"), indent=1, sort_keys=True)
-if mode == "forward":
-    json.dump(out, open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
-if mode == "train_f32":
-    json.dump(out, open(os.path.join(root, "profiles", "pmc_train_latest.json"), "w"), indent=1, sort_keys=True)
+# the summaries bench.py reads for `roofline.traffic` (one per leg)
+latest = {"forward": "pmc_latest.json", "fwd_f32": "pmc_latest.json", "train_f32": "pmc_train_latest.json",
+          "fwd_bf16": "pmc_bf16_fwd_latest.json", "train_bf16": "pmc_bf16_train_latest.json"}
+if mode in latest:
+    json.dump(out, open(os.path.join(root, "profiles", latest[mode]), "w"), indent=1, sort_keys=True)
 for k in sorted(out):
     if "field" in k or k.startswith("k_dw"):
         print(k, json.dumps(out[k], sort_keys=True))

@@ -35,7 +35,7 @@ def test_forward_stream_32x32x16():
 def test_backward_stream():
     c, _ = _consts(os.path.join(CSRC, "bf16_common.h"))
     segs = [("BBS_COLT", 4 * 4), ("BBS_FOLDT", 8 * 9), ("BBS_L7T", 3 * 8 * 16), ("BBS_L4T", 8 * 16),
-            ("BBS_L3T", 3 * 8 * 16), ("BBS_G0T", 2 * 16), ("BBS_G4T", 2 * 16)]
+            ("BBS_L3T", 3 * 8 * 16), ("BBS_G0T", 2 * 32)]
     pos = 0
     for name, n in segs:
         assert c[name] == pos, name
