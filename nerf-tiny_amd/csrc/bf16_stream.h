@@ -80,6 +80,24 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_d
                : "memory");
 }
 
+// the same with the non-temporal hint (once-read streams: the weight-gradient kernels' operands)
+__device__ __forceinline__ void glds16_nt(const unsigned char* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// a 16-byte store of a saved piece: plain, or (NERF_NT_SAVE_STORES, timing experiment) with the non-temporal hint
+__device__ __forceinline__ void store_piece(unsigned char* dst, const u32x4& v) {
+#ifdef NERF_NT_SAVE_STORES
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+#else
+  *reinterpret_cast<u32x4*>(dst) = v;
+#endif
+}
+
 // this wave's two 1-KiB pieces of chunk c -> ring slot c % S::NS  (S::RING_OFF = LDS offset of the ring)
 template <class S>
 __device__ __forceinline__ void bf_dma_chunk(const BfCtx& c, int chunk) {

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
 
   unsigned char* const gvl = a.bG + lane * 16;
   auto grad_piece = [&](int tensor, int ks, const u32x4& v) {
-    *reinterpret_cast<u32x4*>(gvl + ((size_t)a.wb_tot * bg_cum(tensor) + (size_t)wb * bg_ks(tensor) + ks) * BF_FRAG_BYTES) = v;
+    store_piece(gvl + ((size_t)a.wb_tot * bg_cum(tensor) + (size_t)wb * bg_ks(tensor) + ks) * BF_FRAG_BYTES, v);
   };
   grad_piece(BG_Z, 0, zin[0]);
   grad_piece(BG_Z, 1, zin[1]);

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   unsigned char* const mkl = SAVE ? reinterpret_cast<unsigned char*>(a.bmask) + lane * 16 : nullptr;
   unsigned mw[4] = {0u, 0u, 0u, 0u};
   auto save_piece = [&](int tensor, int ks, const u32x4& v) {
-    *reinterpret_cast<u32x4*>(svl + ((size_t)a.wb_tot * bs_cum(tensor) + (size_t)wb * bs_ks(tensor) + ks) * BF_FRAG_BYTES) = v;
+    store_piece(svl + ((size_t)a.wb_tot * bs_cum(tensor) + (size_t)wb * bs_ks(tensor) + ks) * BF_FRAG_BYTES, v);
   };
   if (SAVE) {
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
           mw[f >> 1] = alive_bits(A);
         if (f == ntiles - 1) {  // the layer's output is complete: one contiguous burst
           u32x4 mv = {mw[0], mw[1], ntiles > 4 ? mw[2] : 0u, ntiles > 4 ? mw[3] : 0u};
-          *reinterpret_cast<u32x4*>(mkl + ((size_t)mlayer * a.wb_tot + wb) * 1024) = mv;
+          store_piece(mkl + ((size_t)mlayer * a.wb_tot + wb) * 1024, mv);
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks)
             if (ks < 2 * ntiles) save_piece(tensor, ks, out[ks]);

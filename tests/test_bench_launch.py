@@ -46,8 +46,15 @@ def test_train_traffic_lookup_matches_the_shipped_kernel_names():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    t = bench.read_traffic(list(bench.DW_LAUNCHES), train=True, scale=bench.DW_LAUNCHES)
-    assert t is not None and 10e9 < t < 40e9, t  # 18.1 GB per step measured
-    for keys in (["k_field_fwd"], ["k_field_bwd_reg<true>", "k_field_bwd_reg<false>"]):
-        assert bench.read_traffic(keys, train=True) is not None, keys
-    assert bench.read_traffic(["k_field_fwd"]) is not None
+    f32_train, f32_fwd, bf_train, bf_fwd = bench.Leg("t", True, False), bench.Leg("f", False, False), bench.Leg("bt", True, True), bench.Leg("bf", False, True)
+    t = bench.read_traffic(f32_train, list(bench.DW_LAUNCHES), scale=bench.DW_LAUNCHES)
+    assert t is not None and 10e9 < t < 40e9, t  # 16.2 GB per step measured (profiles/r03_train_f32_pmc.json)
+    for keys in (["k_field_fwd_reg<true, false>"], ["k_field_bwd_reg<true>", "k_field_bwd_reg<false>"]):
+        assert bench.read_traffic(f32_train, keys) is not None, keys
+    assert bench.read_traffic(f32_fwd, ["k_field_fwd"]) is not None
+    # the bf16-MLP legs (cfg3) carry measured traffic as well: no null, no computed stand-in
+    tb = bench.read_traffic(bf_train, list(bench.DW_BF16_LAUNCHES), scale=bench.DW_BF16_LAUNCHES)
+    assert tb is not None and 4e9 < tb < 12e9, tb  # 7.6 GB per step measured (profiles/r03_train_bf16_pmc.json)
+    for keys in (["k_field_fwd_bf16<true>"], ["k_field_bwd_bf16<true>", "k_field_bwd_bf16<false>"]):
+        assert bench.read_traffic(bf_train, keys) is not None, keys
+    assert bench.read_traffic(bf_fwd, ["k_field_fwd_bf16x"]) is not None
