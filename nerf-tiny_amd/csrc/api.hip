@@ -476,9 +476,18 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     auto X = [&](int t) { return bs + (size_t)wb_tot * bs_cum(t) * BF_FRAG_BYTES; };
     auto Gt = [&](int t) { return bg + (size_t)wb_tot * bg_cum(t) * BF_FRAG_BYTES; };
     int ns = 0;
+    // every product writes its own slab region; ONE launch sums them all at the end
+    DwBfReduceBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    auto red = [&](const float* sl, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count, float* dW, int ldw, int col0, float* db) {
+      DwBfReduceArgs& r = rb.r[rb.n++];
+      r.slabs = sl; r.nslab = nslab; r.rows = rows; r.ni = ni; r.o_first = o_first; r.o_count = o_count; r.i_first = i_first; r.i_count = i_count;
+      r.dW = dW; r.ldw = ldw; r.col0 = col0; r.db = db;
+    };
     // layer 0: X = gamma_p
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1], st));
+    red(slabs, ns, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1]);
+    slabs += (size_t)ns * 256 * 65;
     {  // layers 1, 2, 3, 5, 6, 7: six 256 x 256 products in ONE launch (42 workgroups each: a sixth of the slab traffic)
       static const int layers[6] = {1, 2, 3, 5, 6, 7};
       const unsigned char* Gs[6];
@@ -486,28 +495,31 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
       for (int k = 0; k < 6; ++k) { Gs[k] = Gt(BG_L0 + layers[k]); Xs[k] = X(BS_H0 + layers[k] - 1); }
       HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st));
       for (int k = 0; k < 6; ++k)
-        HIP_TRY(launch_dw_bf16_reduce(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dw[2 * layers[k]], WIDTH, 0,
-                                      dw[2 * layers[k] + 1], st));
+        red(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dw[2 * layers[k]], WIDTH, 0, dw[2 * layers[k] + 1]);
+      slabs += (size_t)6 * ns * 256 * 257;
     }
     // layer 4: one pass over dpre4 for both column groups of the [256][316] matrix: X = [h3 | gamma_p]
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9], st));
+    red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
+    slabs += (size_t)ns * 256 * 321;
     // point_info folded into dir_info (bf16_common.h): ONE product dpre_dir^T [gamma_d | h7] -- columns 0..23 are dir_info's direction
     // columns, columns 32.. are M = dpre_dir^T h7 (-> k_fold_grads below) -- and in the same pass over h7 the sigma head: row 3 of h7^T (dz, dspre)
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), wb_tot, slabs, &ns, st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR], st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 160, 288, 0, HALF, 32, WIDTH, at<float>(ws, L.mbuf), WIDTH, 0, nullptr, st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 160, 288, HALF + 3, 1, 32, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr, st));
+    red(slabs, ns, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR]);
+    red(slabs, ns, 160, 288, 0, HALF, 32, WIDTH, at<float>(ws, L.mbuf), WIDTH, 0, nullptr);
+    red(slabs, ns, 160, 288, HALF + 3, 1, 32, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr);
+    slabs += (size_t)ns * 160 * 289;
+    // colour head = rows 0..2 of the (dz, dspre) tile against c; row 3 of its column sums = the sigma bias gradient
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
+    red(slabs, ns, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR]);
+    red(slabs, ns, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA]);
+    HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
     {
       FoldGradArgs fg;
       fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
       fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
       HIP_TRY(launch_fold_grads(fg, st));
     }
-    // colour head = rows 0..2 of the (dz, dspre) tile against c; row 3 of its column sums = the sigma bias gradient
-    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR], st));
-    HIP_TRY(launch_dw_bf16_reduce(slabs, ns, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA], st));
   } else {
     ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
     DwBatch batch;

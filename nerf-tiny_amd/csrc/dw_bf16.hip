@@ -176,15 +176,6 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
   }
 }
 
-// dW[o][col0 + i - i_first] = sum over slabs of row o_first + o, column i; db[o] likewise from the last slab column
-struct DwBfReduceArgs {
-  const float* slabs;
-  int nslab, rows, ni;          // slab = [rows][ni + 1]
-  int o_first, o_count, i_first, i_count;   // slab columns [i_first, i_first + i_count) -> dW columns col0 ..
-  float* dW; int ldw, col0;
-  float* db;                    // or null
-};
-
 // 64 output elements per block; the slabs are split over 4 thread groups whose partial sums are added in a fixed order
 __global__ __launch_bounds__(256) void k_dw_bf16_reduce(const DwBfReduceArgs a) {
   __shared__ float part[4][64];
@@ -221,7 +212,60 @@ __global__ __launch_bounds__(256) void k_dw_bf16_reduce(const DwBfReduceArgs a) 
   }
 }
 
-size_t dw_bf16_slab_floats() { return (size_t)DWB_WGS * (256 + 32) * (320 + 1); }  // also covers 6 x 42 slabs of 256 x 257 and (128 + 32) x 289
+// ONE launch for all slab sums of a step: blockIdx.y = descriptor (the thirteen per-product launches cost 90 us per step in launch
+// gaps and tiny grids -- a quarter of the weight-gradient phase of a 512-ray step)
+__global__ __launch_bounds__(256) void k_dw_bf16_reduce_batch(const DwBfReduceBatch b) {
+  __shared__ float part[4][64];
+  const DwBfReduceArgs& a = b.r[blockIdx.y];
+  const int ld = a.ni + 1;
+  if ((int)blockIdx.x * 64 >= a.o_count * ld) return;  // (block-uniform)
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  const bool in_range = idx < a.o_count * ld;
+  const int o = in_range ? idx / ld : 0, i = in_range ? idx - o * ld : 0;
+  const bool wanted = in_range && ((i < a.ni && i >= a.i_first && i < a.i_first + a.i_count && a.dW != nullptr) || (i == a.ni && a.db != nullptr));
+  float s = 0.f;
+  if (wanted) {
+    const float* p = a.slabs + (size_t)(a.o_first + o) * ld + i;
+    const size_t stride = (size_t)a.rows * ld;
+    const int per = (a.nslab + 3) / 4, k0 = grp * per, k1 = min(a.nslab, k0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      s0 += p[(size_t)k * stride];
+      s1 += p[(size_t)(k + 1) * stride];
+      s2 += p[(size_t)(k + 2) * stride];
+      s3 += p[(size_t)(k + 3) * stride];
+    }
+    for (; k < k1; ++k) s0 += p[(size_t)k * stride];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && wanted) {
+    const float t = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    if (i == a.ni)
+      a.db[o] = t;
+    else
+      a.dW[(size_t)o * a.ldw + a.col0 + (i - a.i_first)] = t;
+  }
+}
+
+hipError_t launch_dw_bf16_reduce_batch(const DwBfReduceBatch& b, hipStream_t st) {
+  int most = 1;
+  for (int k = 0; k < b.n; ++k) {
+    const int blocks = (b.r[k].o_count * (b.r[k].ni + 1) + 63) / 64;
+    most = blocks > most ? blocks : most;
+  }
+  hipLaunchKernelGGL(k_dw_bf16_reduce_batch, dim3(most, b.n), dim3(256), 0, st, b);
+  return hipGetLastError();
+}
+
+// every product of a step keeps its own slabs (ONE reduce launch at the end): layer 0, the six grouped 256 x 256 products, layer 4, the
+// folded dpre_dir product with the sigma rows, the colour head
+size_t dw_bf16_slab_floats() {
+  return (size_t)DWB_WGS * 256 * 65 + (size_t)6 * (DWB_WGS / 6) * 256 * 257 + (size_t)DWB_WGS * 256 * 321 + (size_t)DWB_WGS * 160 * 289 + (size_t)DWB_WGS * 32 * 129;
+}
 
 template <int NIT, bool HAS_Z>
 static hipError_t dwb_launch(const DwBfArgs& a, int wgs, hipStream_t st) {

@@ -244,6 +244,16 @@ hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned c
                                 hipStream_t st);
 hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count,
                                  float* dW, int ldw, int col0, float* db, hipStream_t st);
+// dW[o][col0 + i - i_first] = sum over slabs of row o_first + o, column i; db[o] likewise from the last slab column
+struct DwBfReduceArgs {
+  const float* slabs;
+  int nslab, rows, ni;          // slab = [rows][ni + 1]
+  int o_first, o_count, i_first, i_count;   // slab columns [i_first, i_first + i_count) -> dW columns col0 ..
+  float* dW; int ldw, col0;
+  float* db;                    // or null
+};
+struct DwBfReduceBatch { DwBfReduceArgs r[16]; int n; };
+hipError_t launch_dw_bf16_reduce_batch(const DwBfReduceBatch& b, hipStream_t st);  // all slab sums of a step in ONE launch
 hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st);  // every product -> its slabs, ONE launch
 hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st);                         // all slabs of the step -> gradients
 size_t dw_item_slab_floats(const DwItem& p);
