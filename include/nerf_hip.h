@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 2 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16 */
+#define NERF_HIP_ABI_VERSION 3 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap */
 
 enum {
   NERF_HIP_OK = 0,
@@ -113,6 +113,19 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
 int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, const float* dC_fine,
                       const float* ray0_near_far, int B, int Nc, int Nf, float last_delta,
                       float* const* dweights24, void* ws, size_t ws_bytes, int flags, void* stream);
+
+/*
+ * nerf_hip_backward for a data-parallel trainer that overlaps its gradient all-reduce with the rest of the backward pass
+ * (the collective sits where the reference has loss.backward(); optimizer.step(), nerf.py:473-474): the gradients of
+ * point_layer[0..7] (tensors 0..15 of dweights24: 491,520 of the 593,924 parameters) are FINAL at the point where
+ * `early_event` (a hipEvent_t created by the caller) is recorded on `stream`; the remaining weight-gradient products (sigma
+ * head, point_info, dir_info, colour head: tensors 16..23) follow it.  A caller puts the all-reduce of tensors 0..15 on another
+ * stream behind that event and the all-reduce of tensors 16..23 behind the call.  early_event == NULL: nerf_hip_backward.
+ */
+int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coarse, const float* dC_fine,
+                              const float* ray0_near_far, int B, int Nc, int Nf, float last_delta,
+                              float* const* dweights24, void* ws, size_t ws_bytes, int flags, void* stream,
+                              void* early_event);
 
 /* ray_loss (nerf.py:325-331) and its gradient: loss[1] = sum (C_c-C*)^2 + sum (C_f-C*)^2,
  * dC_c = 2 (C_c - C*), dC_f = 2 (C_f - C*).  dC_* may be NULL. */

@@ -58,6 +58,7 @@ size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 // The eleven weight-gradient products of the fp32 train step (dw_f32.hip) -- ten MFMA-bound ones, one of them carrying the sigma
 // head, + the thin colour head -- in launch order, with their slab offsets; pointers are filled in by nerf_hip_backward (null
 // here: only sizes matter for the layout).
+constexpr int DW_EARLY_ITEMS = 9;  // layers 1..7, layer 4's skip columns, layer 0 = every tensor of point_layer[0..7]
 long long build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw, float* mbuf) {
   memset(&b, 0, sizeof(b));
   auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db) -> DwItem& {
@@ -396,6 +397,12 @@ int nerf_hip_profile_end(double* ms_sum, int* count, int n_kernels) {
 int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, const float* dC_fine, const float* ray0_near_far,
                       int B, int Nc, int Nf, float last_delta, float* const* dweights24, void* ws, size_t ws_bytes, int flags,
                       void* stream) {
+  return nerf_hip_backward_overlap(weights24, dC_coarse, dC_fine, ray0_near_far, B, Nc, Nf, last_delta, dweights24, ws, ws_bytes, flags, stream, nullptr);
+}
+
+int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coarse, const float* dC_fine, const float* ray0_near_far,
+                              int B, int Nc, int Nf, float last_delta, float* const* dweights24, void* ws, size_t ws_bytes, int flags,
+                              void* stream, void* early_event) {
   if (int rc = check_sizes(B, Nc, Nf)) return rc;
   if (int rc = check_weights(weights24)) return rc;
   if (int rc = check_weights(const_cast<const float* const*>(dweights24))) return rc;
@@ -502,6 +509,11 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
     red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
     slabs += (size_t)ns * 256 * 321;
+    if (early_event) {  // point_layer[0..7] are complete here: their sums go out now, the rest of the products follow the event
+      HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
+      HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(early_event), st));
+      rb.n = 0;
+    }
     // point_info folded into dir_info (bf16_common.h): ONE product dpre_dir^T [gamma_d | h7] -- columns 0..23 are dir_info's direction
     // columns, columns 32.. are M = dpre_dir^T h7 (-> k_fold_grads below) -- and in the same pass over h7 the sigma head: row 3 of h7^T (dz, dspre)
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), wb_tot, slabs, &ns, st));
@@ -538,8 +550,16 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
         ray_duty = true;
       }
     }
-    HIP_TRY(launch_dw(batch, Mtot, slabs, st));
-    HIP_TRY(launch_dw_reduce(batch, st));
+    if (early_event) {  // the first nine products are point_layer[0..7] (build_dw_batch): reduce them, signal, then the rest
+      HIP_TRY(launch_dw(batch, Mtot, slabs, st, 0, DW_EARLY_ITEMS));
+      HIP_TRY(launch_dw_reduce(batch, st, 0, DW_EARLY_ITEMS));
+      HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(early_event), st));
+      HIP_TRY(launch_dw(batch, Mtot, slabs, st, DW_EARLY_ITEMS, batch.n - DW_EARLY_ITEMS));
+      HIP_TRY(launch_dw_reduce(batch, st, DW_EARLY_ITEMS, batch.n - DW_EARLY_ITEMS));
+    } else {
+      HIP_TRY(launch_dw(batch, Mtot, slabs, st));
+      HIP_TRY(launch_dw_reduce(batch, st));
+    }
     FoldGradArgs fg;
     fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
     fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];

@@ -699,8 +699,9 @@ hipError_t launch_fold_grads(const FoldGradArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st) {
-  for (int i = 0; i < b.n; ++i) {
+hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st, int first, int count) {
+  const int last = count < 0 ? b.n : first + count;
+  for (int i = first; i < last; ++i) {
     const DwItem& p = b.item[i];
     if (p.thin) hipLaunchKernelGGL(k_dw_thin, dim3(p.nwg), dim3(512), 0, st, p, Mtot, slabs);
     else if (dwi_ncb(p) == 4 && p.has_sig && p.nout == 128) hipLaunchKernelGGL((k_dw4<4, true>), dim3(p.nwg), dim3(256), 0, st, p, Mtot, slabs);
@@ -712,7 +713,12 @@ hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t
   return hipSuccess;
 }
 
-hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st) {
+hipError_t launch_dw_reduce(const DwBatch& b_in, hipStream_t st, int first, int count) {
+  // items [first, first + count) (count < 0: all): the kernel indexes items with blockIdx.y, so the range is shifted to the front
+  DwBatch b = b_in;
+  const int last = count < 0 ? b_in.n : first + count;
+  b.n = last - first;
+  for (int i = 0; i < b.n; ++i) b.item[i] = b_in.item[first + i];
   int most = 0;
   for (int i = 0; i < b.n; ++i) {
     const DwItem& p = b.item[i];

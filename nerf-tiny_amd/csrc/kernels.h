@@ -254,8 +254,8 @@ struct DwBfReduceArgs {
 };
 struct DwBfReduceBatch { DwBfReduceArgs r[16]; int n; };
 hipError_t launch_dw_bf16_reduce_batch(const DwBfReduceBatch& b, hipStream_t st);  // all slab sums of a step in ONE launch
-hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st);  // every product -> its slabs, ONE launch
-hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st);                         // all slabs of the step -> gradients
+hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st, int first = 0, int count = -1);  // products [first, first + count) -> their slabs
+hipError_t launch_dw_reduce(const DwBatch& b, hipStream_t st, int first = 0, int count = -1);  // the slabs of items [first, first + count) -> gradients, ONE launch
 size_t dw_item_slab_floats(const DwItem& p);
 bool dw_ray_duty_ok(const DwItem& p, long long Mtot, int B, int Nc, int Nf);  // may the product of G_dir carry the per-ray sums?
 hipError_t launch_small_grads(const SmallGradArgs& a, float* scratch, hipStream_t st);  // scratch: >= 128 * 128 * 24 floats (the slab buffer, after the reduce)

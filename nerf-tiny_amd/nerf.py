@@ -127,9 +127,11 @@ class _RenderFn(torch.autograd.Function):
         dC_c = dC_c.contiguous().float()
         dC_f = dC_f.contiguous().float()
         stream = torch.cuda.current_stream(dC_c.device).cuda_stream
-        _abi.check(_abi.lib().nerf_hip_backward(_abi.ptr_array(params), dC_c.data_ptr(), dC_f.data_ptr(), ctx.ray0, ctx.B,
-                                                model.num_coarse, model.num_fine, LAST_DELTA, _abi.ptr_array(grads),
-                                                ctx.ws.data_ptr(), ctx.ws.numel(), ctx.flags, stream))
+        # a bucket with overlap enabled gets the event at which point_layer[0..7]'s gradients are final (parallel.GradBucket)
+        early = bucket.early_event_handle if bucket is not None else 0
+        _abi.check(_abi.lib().nerf_hip_backward_overlap(_abi.ptr_array(params), dC_c.data_ptr(), dC_f.data_ptr(), ctx.ray0, ctx.B,
+                                                        model.num_coarse, model.num_fine, LAST_DELTA, _abi.ptr_array(grads),
+                                                        ctx.ws.data_ptr(), ctx.ws.numel(), ctx.flags, stream, early or None))
         if bucket is not None:
             # p.grad IS the bucket view (overwritten every step, like the C ABI's dweights24): nothing for autograd to accumulate
             for p, v in zip(params, grads):

@@ -29,6 +29,9 @@ def global_ray0(poses_bound: torch.Tensor) -> tuple[float, float]:
     return float(pb0[15]), float(pb0[16])
 
 
+EARLY_TENSORS = 16  # point_layer[0..7].{weight, bias}: final before the rest (include/nerf_hip.h: nerf_hip_backward_overlap)
+
+
 class GradBucket:
     """One flat fp32 buffer holding the gradients of `params` (in parameters() order) so that a single all-reduce moves
     all 2.27 MiB (latency-bound on xGMI: one collective instead of 24).  With ``model.grad_bucket = bucket`` the backward
@@ -50,6 +53,29 @@ class GradBucket:
         #: a backward has written gradients into the views that nothing has consumed yet (all-reduce / optimizer step).  A second
         #: backward into the same bucket would OVERWRITE them (the kernels store, they do not accumulate): _RenderFn.backward raises.
         self.pending = False
+        #: first float of the LATE part of the flat buffer: tensors 0..15 (point_layer[0..7], 83 % of the parameters) are final
+        #: before the last weight-gradient products of a backward run (nerf_hip_backward_overlap), tensors 16.. after it
+        self.early_numel = offs[EARLY_TENSORS] if len(offs) > EARLY_TENSORS else o
+        self.early_event = None   # torch.cuda.Event recorded by the library where the early part is final (enable_overlap)
+        self.side_stream = None
+
+    def enable_overlap(self):
+        """Overlap the all-reduce of the early part with the rest of the backward pass: the library records `early_event` on the
+        compute stream once point_layer[0..7]'s gradients are final; `allreduce_sum` then runs that part's collective on a side stream
+        behind the event while the compute stream finishes the remaining products, and only the small late part (sigma head,
+        point_info, dir_info, colour head: 17 % of the bytes) is reduced after the backward.  CUDA/ROCm tensors only."""
+        if self.flat.device.type != "cuda":
+            return self
+        if self.early_event is None:
+            self.early_event = torch.cuda.Event()
+            self.early_event.record(torch.cuda.current_stream(self.flat.device))  # torch creates the HIP event at its first record
+            self.side_stream = torch.cuda.Stream(self.flat.device)
+        return self
+
+    @property
+    def early_event_handle(self):
+        """hipEvent_t of `early_event` for the C ABI (0 = no overlap)."""
+        return int(self.early_event.cuda_event) if self.early_event is not None else 0
 
     def consume(self):
         """The gradients in the views have been used (optimizer step, all-reduce, or deliberately dropped): the next backward may
@@ -68,6 +94,20 @@ class GradBucket:
             p.grad.copy_(v)
 
     def allreduce_sum(self, group=None):
+        """SUM over the ranks, in place.  With `enable_overlap()` and gradients the kernels wrote straight into the views: the early
+        part's collective runs on the side stream behind the library's event (i.e. beside the last weight-gradient products), the
+        late part's on the current stream; the current stream then waits for both.  Otherwise ONE collective over the whole buffer."""
+        foreign = self._foreign()
+        if self.early_event is not None and not foreign and 0 < self.early_numel < self.flat.numel():
+            cur = torch.cuda.current_stream(self.flat.device)
+            self.side_stream.wait_event(self.early_event)
+            with torch.cuda.stream(self.side_stream):
+                w = dist.all_reduce(self.flat[: self.early_numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            dist.all_reduce(self.flat[self.early_numel:], op=dist.ReduceOp.SUM, group=group)
+            with torch.cuda.stream(cur):
+                w.wait()  # the current stream waits for the side stream's collective
+            self.consume()
+            return
         self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.unpack()

@@ -41,9 +41,13 @@ def _worker(rank, world, port, q):
             p.grad = (rank + 1) * g.clone()
         b = par.GradBucket(params)
         assert b.numel == 593924 and b.numel <= b.flat.numel() < b.numel + 64 * 24 and all((v.data_ptr() - b.flat.data_ptr()) % 256 == 0 for v in b.views)
+        # the early / late split of the buffer (overlapped collective on a GPU): point_layer[0..7] = the first 16 tensors; on the CPU
+        # enable_overlap() is a no-op and allreduce_sum stays one collective
+        ok0 = b.early_numel == (b.views[16].data_ptr() - b.flat.data_ptr()) // 4 and b.early_numel >= sum(p.numel() for p in params[:16]) == 491520
+        ok0 &= b.enable_overlap() is b and b.early_event is None and b.early_event_handle == 0
         b.allreduce_sum()
         tot = sum(range(1, world + 1))
-        ok = all(torch.allclose(p.grad, tot * g, rtol=1e-6, atol=1e-7) for p, g in zip(params, base))
+        ok = ok0 and all(torch.allclose(p.grad, tot * g, rtol=1e-6, atol=1e-7) for p, g in zip(params, base))
         # shards cover [0, n) exactly, in order
         n = 1003
         bounds = [par.shard_bounds(n, r, world) for r in range(world)]

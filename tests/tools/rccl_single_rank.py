@@ -82,6 +82,25 @@ def main():
     assert all(torch.isfinite(p.grad).all() for p in m1.network.parameters())
     assert not torch.equal(m1.network.point_info.weight.grad, ref[18])
 
+    # (d2) the overlapped collective: point_layer[0..7]'s part of the buffer is reduced on a side stream behind the library's
+    # event (nerf_hip_backward_overlap), the rest behind the call -- same gradients as the single collective, fp32 and bf16
+    for bf in (False, True):
+        m3 = model(B)
+        m3.bf16_mlp = bf
+        b_plain = par.GradBucket(m3.network.parameters())
+        par.train_step_sharded(m3, b_plain, row, col, pbd, K, Ctd, rank=0, world=1)
+        torch.cuda.synchronize()
+        want = b_plain.flat.clone()
+        b_ov = par.GradBucket(m3.network.parameters()).enable_overlap()
+        assert b_ov.early_event_handle != 0 and 0 < b_ov.early_numel < b_ov.flat.numel()
+        n_early = sum(p.numel() for p in list(m3.network.parameters())[:16])
+        assert n_early == 491520 and b_ov.early_numel >= n_early
+        for _ in range(3):  # repeated steps: the event and the side stream are reused
+            par.train_step_sharded(m3, b_ov, row, col, pbd, K, Ctd, rank=0, world=1)
+        torch.cuda.synchronize()
+        assert same(b_ov.flat, want), f"overlapped all-reduce changed the gradients (bf16={bf})"
+        assert not b_ov.pending
+
     # (e) the fused optimizer steps from the bucket views
     opt = P.FusedAdam(list(m1.network.parameters()), lr=1e-3)
     before = m1.network.point_info.weight.detach().clone()
@@ -90,7 +109,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
-    print("RCCL-OK single-rank nccl group: bucketed backward, all-reduce, shard sum, bf16, fused Adam")
+    print("RCCL-OK single-rank nccl group: bucketed backward, all-reduce, overlapped all-reduce, shard sum, bf16, fused Adam")
 
 
 if __name__ == "__main__":
