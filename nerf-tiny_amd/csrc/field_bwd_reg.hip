@@ -58,8 +58,7 @@ __device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, co
     if (grow != nullptr) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) =
-            make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
+        store_row4(grow + 32 * t + 8 * g, make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]));
     }
     if (MASK_IN) mw = mn;
   };
@@ -121,8 +120,7 @@ __device__ __forceinline__ void reg_layer_bwd_thin(const float4* __restrict__ se
     if (STORE) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) =
-            make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
+        store_row4(grow + 32 * t + 8 * g, make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]));
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(tin[t & 1][r]));
@@ -344,7 +342,7 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
         v.y = ((mb0[t] >> (4 * g + 1)) & 1u) ? A[t][4 * g + 1] : 0.f;
         v.z = ((mb0[t] >> (4 * g + 2)) & 1u) ? A[t][4 * g + 2] : 0.f;
         v.w = ((mb0[t] >> (4 * g + 3)) & 1u) ? A[t][4 * g + 3] : 0.f;
-        *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) = v;
+        store_row4(grow + 32 * t + 8 * g, v);
       }
   }
 #ifdef NERF_STAMPS

@@ -5,6 +5,18 @@
 namespace nerf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// 16-byte store of a saved activation / gradient group of the fp32 training kernels (written once, read once by the weight-gradient
+// kernels): plain by default; NERF_F32_NT_SAVES (timing experiment) = with the non-temporal hint, as the bf16 saves
+__device__ __forceinline__ void store_row4(float* dst, const float4& v) {
+#ifdef NERF_F32_NT_SAVES
+  const f32x4v q = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(q, reinterpret_cast<f32x4v*>(dst));
+#else
+  *reinterpret_cast<float4*>(dst) = v;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------
 // building blocks of the fused kernels

@@ -80,8 +80,7 @@ __device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const 
     if (SAVE) {  // compile-time: a SAVE layer always has rows, a SAVE && RELU_IN layer always has masks (no null tests in the stream)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(sv.rows + 32 * t + 8 * g) =
-            make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]);
+        store_row4(sv.rows + 32 * t + 8 * g, make_float4(tin[t & 1][4 * g], tin[t & 1][4 * g + 1], tin[t & 1][4 * g + 2], tin[t & 1][4 * g + 3]));
       if (RELU_IN) {
         unsigned bits = 0;
 #pragma unroll
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
         const float4 q2 = *reinterpret_cast<const float4*>(wc + 2 * HALF + 32 * t + 8 * g);
         const float c0 = relu1(A[t][4 * g + 0]), c1 = relu1(A[t][4 * g + 1]);
         const float c2 = relu1(A[t][4 * g + 2]), c3 = relu1(A[t][4 * g + 3]);
-        if (SAVE) *reinterpret_cast<float4*>(srow + S_C * MS + 32 * t + 8 * g) = make_float4(c0, c1, c2, c3);
+        if (SAVE) store_row4(srow + S_C * MS + 32 * t + 8 * g, make_float4(c0, c1, c2, c3));
         z0 = __builtin_fmaf(c3, q0.w, __builtin_fmaf(c2, q0.z, __builtin_fmaf(c1, q0.y, __builtin_fmaf(c0, q0.x, z0))));
         z1 = __builtin_fmaf(c3, q1.w, __builtin_fmaf(c2, q1.z, __builtin_fmaf(c1, q1.y, __builtin_fmaf(c0, q1.x, z1))));
         z2 = __builtin_fmaf(c3, q2.w, __builtin_fmaf(c2, q2.z, __builtin_fmaf(c1, q2.y, __builtin_fmaf(c0, q2.x, z2))));
