@@ -285,9 +285,9 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   memcpy(ra.K, K_inv9, 9 * sizeof(float));
   ra.B = B; ra.Nc = Nc;
   ra.rayf = at<float>(ws, L.rayf);
-  ra.dvec = at<float>(ws, L.dvec);
+  ra.dvec = bf16 ? nullptr : at<float>(ws, L.dvec);  // (the bf16 kernels run the direction columns as MFMA k-steps: no per-ray start vector)
   ra.w_dir = w.p[W_DIR]; ra.b_dir = w.p[B_DIR];
-  ra.b_fold = bf16 ? nullptr : at<float>(ws, L.fold);  // (the bf16 kernels do not read dvec)
+  ra.b_fold = at<float>(ws, L.fold);
   ra.t_c = at<float>(ws, L.t_c);
   ra.status = at<unsigned>(ws, L.status);  // zeroed by the kernel (the later kernels OR their flags into it)
   { ProfScope ps(NERF_HIP_K_RAYS, st, &pc); HIP_TRY(launch_rays(ra, st)); }
