@@ -311,6 +311,11 @@ def rooflines(leg, prof, b_local, steps):
     fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
                FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key)
     fwd["executed_flop_frac"] = round(EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE, 4)
+    fwd["achieved_executed"] = round(fwd["achieved"] * EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE, 2)
+    fwd["frac_executed"] = round(fwd["frac"] * EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE, 4)
+    fwd["note"] = ("achieved / frac count the ALGORITHMIC FLOPs of the reference's network (SURVEY.md 8d); the kernel executes 8/9 of them "
+                   "(point_info folded into dir_info, DESIGN.md 3a): achieved_executed / frac_executed are the MFMA pipe's side, the figure the "
+                   "MFMA-busy counter corroborates")
     if not leg.train:
         return fwd, None
     sfx = "bf16" if leg.bf16 else "reg"
@@ -337,6 +342,13 @@ def rooflines(leg, prof, b_local, steps):
               "traffic": dw_traffic, "traffic_source": dw_src,
               "kernel": "k_dw4 / k_dw_thin / k_dw_reduce / k_fold_grads / k_dir_* (all weight-gradient products of one step incl. the reduce and the thin colour head = one 'launch')",
               "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "flop_per_launch": flop}
+    # executed / algorithmic FLOPs of the other two phases (the fold removes 65,536 MACs per sample from each: DESIGN.md 3a)
+    chain_exec = 1.0 - 2 * 65536 * (NC + NF) / (CHAIN_FLOP_COARSE * NC + CHAIN_FLOP_FINE * NF)
+    for blk, ex in ((chain, chain_exec), (dw, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)):
+        blk["executed_flop_frac"] = round(ex, 4)
+        if blk["bound"] == "mfma":
+            blk["achieved_executed"] = round(blk["achieved"] * ex, 2)
+            blk["frac_executed"] = round(blk["frac"] * ex, 4)
     phases = {"forward_with_saves": fwd, "dx_chain": chain, "dw": dw}
     dominant = max(phases.values(), key=lambda b: b["avg_launch_ms"] * (2 if b is not dw else 1))
     return dominant, phases
@@ -543,7 +555,7 @@ def main():
     # ---- N > 1: the STRONG-scaling form of the same legs in the same line (north_star: ">= 6x strong scaling to 8 GPUs"): ONE 4096-ray
     # batch (the same on every rank) split into contiguous slices of 4096 / N rays, the global ray 0's spacing forwarded, one flat SUM
     # all-reduce per train step where the reference has loss.backward(); optimizer.step() (nerf.py:473-474)
-    if world > 1 and not strong and not args.no_extra and B % world == 0:
+    if dist is not None and not strong and not args.no_extra and B % world == 0:  # (also in the single-rank RCCL rehearsal: same code path)
         g_full = synth_inputs(seed=1000)
         g_full = (g_full[0], g_full[1], g_full[2], g_full[4])
         bs = B // world
@@ -557,7 +569,7 @@ def main():
     # ---- N = 1: what ONE rank of an 8-GPU strong-scaling job does with its share, measured here: 512 rays (4096 / 8) and the reference's
     # own default batch of 400 rays (conf/lego.ini:7), the first rays of the same batch (global ray 0 = local ray 0)
     proxy = None
-    if world == 1 and not strong and not args.no_extra:
+    if world == 1 and dist is None and not strong and not args.no_extra:
         proxy = {}
         t_full = {name: (rep["ms_per_step"] if (train, bf16) == (head.train, head.bf16) else extra[name]["ms_per_step"]) for name, train, bf16, _, _ in legs}
         for bs in (512, 400):
