@@ -293,13 +293,16 @@ def rooflines(leg, prof, b_local, steps):
     peak = PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS
     src = "profiles/" + PMC_FILES[(leg.train, leg.bf16)] + " (committed rocprofv3 --pmc passes of this leg; not re-measured in this run)"
 
+    def scaled(t):  # the PMC passes ran at 4096 rays per step; a smaller batch of this run moves proportionally less (the slabs aside)
+        return None if t is None else int(t * b_local / B)
+
     def mfma(kernel, keys, flop_per_launch, traffic_keys):
         ms = sum(prof.get(k, (0.0, 0))[0] for k in keys)
         n = sum(prof.get(k, (0.0, 0))[1] for k in keys)
         avg = ms / max(n, 1)
         ach = flop_per_launch / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": read_traffic(leg, traffic_keys), "traffic_source": src, "kernel": kernel, "avg_launch_ms": round(avg, 4),
+                "traffic": scaled(read_traffic(leg, traffic_keys)), "traffic_source": src, "kernel": kernel, "avg_launch_ms": round(avg, 4),
                 "launches": n, "flop_per_launch": flop_per_launch}
 
     # dominant forward kernel: launched twice per step (coarse pass B*Nc samples, fine pass B*Nf samples); "launch" = the
@@ -325,7 +328,7 @@ def rooflines(leg, prof, b_local, steps):
     # weight-gradient phase: all dW = G^T X products of one step (same MACs as one forward over all samples) + slab reduces + thin heads
     dw_ms = prof.get("bwd_dw", (0.0, 0))[0] / max(prof.get("bwd_dw", (0.0, 1))[1], 1)
     launches = DW_BF16_LAUNCHES if leg.bf16 else DW_LAUNCHES
-    dw_traffic = read_traffic(leg, list(launches), scale=launches)
+    dw_traffic = scaled(read_traffic(leg, list(launches), scale=launches))
     dw_src = src + "; per step: " + ", ".join(f"{n} x {k}" for k, n in launches.items())
     if leg.bf16:
         # HBM-bound by construction: bytes of bf16 operands per 32-sample wave block, read once each
@@ -349,6 +352,15 @@ def rooflines(leg, prof, b_local, steps):
         if blk["bound"] == "mfma":
             blk["achieved_executed"] = round(blk["achieved"] * ex, 2)
             blk["frac_executed"] = round(blk["frac"] * ex, 4)
+    # which roof binds a phase: its measured HBM bytes per launch (PMC, committed) over THIS run's launch time against 8 TB/s, next to
+    # the MFMA fraction -- the bf16 training kernels move 2-3 GB per launch and sit closer to the HBM roof than to the matrix one
+    for blk in (fwd, chain, dw):
+        if blk.get("traffic") and blk["avg_launch_ms"] > 0:
+            gbs = blk["traffic"] / (blk["avg_launch_ms"] * 1e-3) / 1e9
+            blk["hbm_gbs"] = round(gbs, 1)
+            blk["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
+            if blk["bound"] == "mfma" and blk["hbm_frac"] > blk["frac"]:
+                blk["bound"] = "hbm (by the measured bytes; the MFMA figures are kept in achieved / frac)"
     phases = {"forward_with_saves": fwd, "dx_chain": chain, "dw": dw}
     dominant = max(phases.values(), key=lambda b: b["avg_launch_ms"] * (2 if b is not dw else 1))
     return dominant, phases
@@ -380,6 +392,12 @@ def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong)
            "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in prof.items()}}
     if phases is not None:
         rep["roofline_phases"] = phases
+        tr = [(b.get("traffic"), (1 if k == "dw" else 2)) for k, b in phases.items()]
+        if all(t for t, _ in tr):  # HBM bytes of the three phases of one step (PMC) over this run's step time
+            step_bytes = sum(t * n for t, n in tr)
+            rep["step_hbm"] = {"bytes_per_step": int(step_bytes), "achieved_gbs": round(step_bytes / (elapsed / steps) / 1e9, 1), "peak_gbs": PEAK_HBM_GBS,
+                               "frac": round(step_bytes / (elapsed / steps) / 1e9 / PEAK_HBM_GBS, 4),
+                               "note": "measured HBM traffic of forward-with-saves (x2), dX chain (x2) and the weight-gradient phase, scaled to this run's batch"}
     if leg.train:
         rep["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
         rep["allreduce"] = (f"SUM all-reduce of {N_PARAMS} fp32 gradients (2.27 MiB) over RCCL, world {world}, in two parts: point_layer[0..7] on a side stream "

@@ -64,7 +64,9 @@ struct DwbGeom {
   static constexpr int XKS = 2 * NIT;
   static constexpr int PIECES = 16 + XKS + (HAS_Z ? 2 : 0);   // slot layout: G at piece 0, X at 16, Z at 16 + XKS
   static constexpr int SLOT_BYTES = PIECES * BF_FRAG_BYTES;
-  static constexpr int NSLOT = 4;
+  // ring slots: three blocks in flight are enough where a block is 32+ KiB; the products with small blocks (layer 0: 20 KiB, colour head:
+  // 10 KiB used) were paced by the per-block latency (3.4-3.8 TB/s, profiles/r03_train_bf16_pmc.json): they get as many slots as fit
+  static constexpr int NSLOT = PIECES <= 20 ? 7 : (PIECES <= 26 ? 6 : 4);
   static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;
   static constexpr int NPW = (PIECES + 7) / 8;                // loads per wave and block
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
