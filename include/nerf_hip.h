@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 3 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap */
+#define NERF_HIP_ABI_VERSION 3 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap, NERF_HIP_SPLIT_MLP */
 
 enum {
   NERF_HIP_OK = 0,
@@ -61,6 +61,11 @@ enum {
   NERF_HIP_WEIGHTS_UNCHANGED = 1 << 3, /* nerf_hip_forward only: the caller guarantees that weights24 hold the same values as in the
                                           previous nerf_hip_forward call on this workspace with the same other flags, so the
                                           packed weight image in the workspace is reused instead of rebuilt (rendering loops) */
+  NERF_HIP_SPLIT_MLP = 1 << 4,         /* nerf_hip_forward WITHOUT NERF_HIP_SAVE_FOR_BACKWARD only (inference): the linear layers run on bf16 MFMA
+                                          with every fp32 operand split into two bf16 parts (hi + mid, 16 significant bits) and three
+                                          MFMAs per product, fp32 accumulation -- within the same 1e-4 bar as the exact-fp32 default
+                                          (measured 3e-6 / 2e-5 against the reference's outputs), several times faster; opt-in because
+                                          the default keeps exact k-ordered fp32 fma chains.  Ignored with NERF_HIP_BF16_MLP */
 };
 
 /* status word bits (nerf_hip_read_status) */

@@ -16,6 +16,7 @@ SAVE_FOR_BACKWARD = 1 << 0
 FORCE_TILE_KERNEL = 1 << 1
 BF16_MLP = 1 << 2
 WEIGHTS_UNCHANGED = 1 << 3
+SPLIT_MLP = 1 << 4
 STATUS_RESAMPLE_INDEX = 1 << 0
 
 _p = C.c_void_p

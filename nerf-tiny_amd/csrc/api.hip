@@ -107,6 +107,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
   L.dbg = take(DBG_WORDS * 8);  // diagnostic builds (-DNERF_STAMPS) write cycle stamps here; untouched otherwise
   L.packed = take((size_t)PACKED_ALL_F4 * 16);
   if (flags & NERF_HIP_BF16_MLP) L.packed_bf = take(BF_IMAGE_BYTES);
+  if ((flags & NERF_HIP_SPLIT_MLP) && !(flags & NERF_HIP_BF16_MLP)) L.packed_sp = take(split_image_bytes());
   L.fold = take(FOLD_FLOATS * 4);
   L.rayf = take(b * RAYF * 4);
   L.dvec = take(b * HALF * 4);
@@ -268,12 +269,17 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   const bool bf16 = (flags & NERF_HIP_BF16_MLP) != 0;
   // bf16 inference runs on the 16x16x32 MFMA form (field_fwd_bf16x.hip); NERF_HIP_FORCE_TILE_KERNEL selects the training form
   const bool bf16x = bf16 && !save && !(flags & NERF_HIP_FORCE_TILE_KERNEL);
+  // split-fp32 inference (field_fwd_split.hip): fp32 operands as two bf16 parts, three bf16 MFMAs per product
+  const bool split = (flags & NERF_HIP_SPLIT_MLP) && !bf16;
+  if (split && save) return fail(NERF_HIP_ERR_ARG, "NERF_HIP_SPLIT_MLP is an inference mode: not with NERF_HIP_SAVE_FOR_BACKWARD");
   const Weights24 w = as_w24(weights24);
 
   ProfChain pc;  // the phases below follow each other with nothing in between
   if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED)) {
     ProfScope ps(NERF_HIP_K_PACK, st, &pc);
-    if (bf16) HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));  // fp32 W_fold, b_fold for the bf16 packers (bf16_common.h)
+    if (bf16 || split) HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));  // fp32 W_fold, b_fold for the bf16 / split packers (bf16_common.h)
+    if (split) HIP_TRY(launch_pack_weights_split(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_sp), st));
+    else
     if (bf16 && bf16x) HIP_TRY(launch_pack_weights_bf16x(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
     else if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
     else HIP_TRY(launch_pack_weights(w, at<float>(ws, L.fold), at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
@@ -285,7 +291,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   memcpy(ra.K, K_inv9, 9 * sizeof(float));
   ra.B = B; ra.Nc = Nc;
   ra.rayf = at<float>(ws, L.rayf);
-  ra.dvec = bf16 ? nullptr : at<float>(ws, L.dvec);  // (the bf16 kernels run the direction columns as MFMA k-steps: no per-ray start vector)
+  ra.dvec = (bf16 || split) ? nullptr : at<float>(ws, L.dvec);  // (the bf16 kernels run the direction columns as MFMA k-steps: no per-ray start vector)
   ra.w_dir = w.p[W_DIR]; ra.b_dir = w.p[B_DIR];
   ra.b_fold = at<float>(ws, L.fold);
   ra.t_c = at<float>(ws, L.t_c);
@@ -296,6 +302,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   memset(&fa, 0, sizeof(fa));
   fa.wp = at<float4>(ws, L.packed);
   if (bf16) fa.wbf = at<unsigned char>(ws, L.packed_bf);
+  if (split) fa.wbf = at<unsigned char>(ws, L.packed_sp);
   fa.w = w;
   fa.rayf = at<float>(ws, L.rayf);
   fa.dvec = at<float>(ws, L.dvec);
@@ -319,7 +326,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     }
   }
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  auto field = [&](const FieldArgs& f) { return bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
+  auto field = [&](const FieldArgs& f) { return split ? launch_field_fwd_split(f, st) : bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
   { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st, &pc); HIP_TRY(field(fa)); }
 
   CoarseArgs ca;

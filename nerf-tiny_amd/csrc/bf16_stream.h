@@ -5,6 +5,7 @@
 #include "bf16_common.h"
 #include "field_common.h"
 
+#include <type_traits>
 #include <utility>
 
 namespace nerf {
@@ -59,6 +60,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// DMA pieces per wave and chunk: 16 / (waves per workgroup).  The 8-wave streams say nothing (2); a 4-wave stream sets PW = 4.
+template <class S, class = void> struct BfPW { static constexpr int v = 2; };
+template <class S> struct BfPW<S, std::void_t<decltype(S::PW)>> { static constexpr int v = S::PW; };
+
 struct BfCtx {
   const unsigned char* wimg;  // global: bias block + fragment stream
   unsigned char* lds;         // bias block + ring
@@ -106,9 +111,10 @@ __device__ __forceinline__ void store_piece(unsigned char* dst, const u32x4& v) 
 template <class S>
 __device__ __forceinline__ void bf_dma_chunk(const BfCtx& c, int chunk) {
   const int slot = chunk % S::NS;
+  constexpr int PW = BfPW<S>::v;
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int fr = 2 * c.wv + e;
+  for (int e = 0; e < PW; ++e) {
+    const int fr = PW * c.wv + e;
     glds16(c.wimg + BF_BIAS_BYTES + ((size_t)chunk * BF_CHUNK + fr) * BF_FRAG_BYTES + c.lane * 16,
            c.lds_base + S::RING_OFF + (slot * BF_CHUNK + fr) * BF_FRAG_BYTES);
   }
@@ -120,7 +126,7 @@ __device__ __forceinline__ void bf_dma_chunk(const BfCtx& c, int chunk) {
 template <class S>
 __device__ __forceinline__ constexpr int bf_wait_count(int c) {
   const int last = (c + S::NS - 2 < S::NCHUNK - 1) ? c + S::NS - 2 : S::NCHUNK - 1;  // newest chunk requested so far
-  const int loads = (last >= c + 2) ? 2 * (last - (c + 2) + 1) : 0;                  // younger than chunk c + 1's
+  const int loads = (last >= c + 2) ? BfPW<S>::v * (last - (c + 2) + 1) : 0;         // younger than chunk c + 1's
   // chunk c + 1 was requested at the sync point of chunk c + 2 - NS (or in the prologue)
   const int c_req = c + 2 - S::NS;
   const int now = S::stores_before(c * BF_CHUNK + BF_SYNC_POS);
@@ -146,9 +152,10 @@ __device__ __forceinline__ void bf_sync(const BfCtx& c) {
 template <class S>
 __device__ __forceinline__ void bf_stream_start(const BfCtx& c) {
   if constexpr (S::HAS_BIAS) {
+    constexpr int PW = BfPW<S>::v;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int fr = 2 * c.wv + e;
+    for (int e = 0; e < PW; ++e) {
+      const int fr = PW * c.wv + e;
       glds16(c.wimg + fr * BF_FRAG_BYTES + c.lane * 16, c.lds_base + fr * BF_FRAG_BYTES);
     }
   }
@@ -166,7 +173,7 @@ __device__ __forceinline__ u32x4 bf_frag(const BfCtx& c, int idx) {
 // The wave issued S::PROLOGUE_STORES stores after bf_stream_start.
 template <class S>
 __device__ __forceinline__ void bf_stream_first(const BfCtx& c, u32x4 (&fr)[S::D]) {
-  constexpr int n = 2 * (S::NS - 2) + S::PROLOGUE_STORES;
+  constexpr int n = BfPW<S>::v * (S::NS - 2) + S::PROLOGUE_STORES;
   wait_vmcnt<(n > 63 ? 63 : n)>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");

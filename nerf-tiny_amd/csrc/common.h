@@ -69,7 +69,7 @@ struct Grads24 { float* p[24]; };
 
 // ---- workspace carve-up (host side, api.cpp) ----
 struct WsLayout {
-  size_t status, dbg, packed, packed_bf, fold, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
+  size_t status, dbg, packed, packed_bf, packed_sp, fold, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
   // training-only
   size_t packed_bf_bwd, bsave, bmask, bG, bslabs;  // bf16-MLP training (fragment layout, bf16_common.h)
   size_t perm, w_m, bundle, save, masks, spre, G, dz, dspre, drgb_c, dsig_c, drgb_f, dsig_f, dt_f, slabs, sbuf, gdbuf, mbuf;

@@ -1,0 +1,233 @@
+// field_fwd_split.hip -- INFERENCE forward of the field query with fp32 operands SPLIT into two bf16 parts (MI355X / gfx950).
+//
+// v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate; v_mfma_f32_32x32x16_bf16 is 16x faster and its products of two bf16 values
+// are exact in its fp32 accumulator.  Every fp32 operand x is written as x = hi + mid + (rest), hi = bf16(x), mid = bf16(x - hi):
+// 16 significant bits, |rest| <= 2^-17 |x|.  A fp32 product then is
+//        a b  =  a_hi b_hi + a_hi b_mid + a_mid b_hi  +  O(2^-16 |a b|)
+// i.e. THREE bf16 MFMAs per k-step of 16 instead of eight fp32 MFMAs of k = 2: 96 instead of 512 MFMA cycles, fp32 accumulation,
+// fp32 biases, fp32 everything else.  Measured against the reference's own outputs this evaluation sits where the exact-fp32 kernels
+// sit (C_coarse 3e-6, C_fine 2e-5 max-rel on the golden cfg2 case: tests/test_gpu_split.py; the emulation of exactly this
+// arithmetic in the build container: 3.3e-6 / 2.2e-5) -- the 1e-4 bar is met with the same margin, because what limits both is the
+// conditioning of the fine pass, not the sixteenth bit of a product.  It is an OPT-IN inference mode (NERF_HIP_SPLIT_MLP,
+// model.split_mlp): the default path keeps the exact k-ordered fp32 fma chains, and training always uses them.
+//
+// Machinery: bf16_stream.h (LDS ring of 1-KiB A fragments filled by direct-to-LDS loads, activations in registers, the accumulator
+// of one layer = the operand of the next), in a 4-wave form: ONE wave per SIMD (the two-part activations of a layer's input and
+// output are 2 x 128 registers), 128 samples per workgroup.  The stream interleaves the two parts of every fragment of the bf16
+// layout of bf16_common.h (point_info folded into dir_info: common.h SEG_FOLD): fragment 2 s = hi, 2 s + 1 = mid of step s.
+#include "bf16_stream.h"
+#include "bf16_weights.h"
+
+namespace nerf {
+
+constexpr int SP_NFRAG = 2 * BF_NFRAG;           // 2,112 fragments = 132 chunks
+constexpr int SP_NCHUNK = SP_NFRAG / BF_CHUNK;
+static_assert(SP_NCHUNK * BF_CHUNK == SP_NFRAG, "whole chunks");
+constexpr int SP_WG = 256;                        // 4 waves x 32 samples
+
+struct SplitStream {
+  static constexpr int NFRAG = SP_NFRAG, NCHUNK = SP_NCHUNK, NS = BF_NS, RING_OFF = BF_BIAS_BYTES, D = 6, PW = 4;
+  static constexpr bool HAS_BIAS = true;
+  static constexpr int PROLOGUE_STORES = 0;
+  __device__ static constexpr int stores_before(int) { return 0; }
+};
+static_assert(BF_SYNC_POS % 2 == 0 && SplitStream::D % 2 == 0, "a step's two fragments stay in one chunk / keep their ring parity");
+
+// two fp32 values -> their hi parts (packed bf16 pair) and mid parts
+struct HiMid { unsigned hi, mid; };
+__device__ __forceinline__ HiMid split2(float x0, float x1) {
+  HiMid r;
+  r.hi = pack2(x0, x1);
+  const float h0 = __uint_as_float(r.hi << 16), h1 = __uint_as_float(r.hi & 0xffff0000u);
+  r.mid = pack2(x0 - h0, x1 - h1);
+  return r;
+}
+
+// One segment: NFT output tiles x (KSA + KSB) k-steps starting at STEP S0 (fragments 2 S0 ..); inputs inA (k-steps 0..KSA-1) then
+// inB, each as hi / mid parts.  Per step three MFMAs, the small products first.  Accumulator hand-over as in bf_segment.
+template <class S, int S0, int NFT, int KSA, int KSB, int BT0, int P0, int NEXT_BT, class Epi, class PrevEpi>
+__device__ __forceinline__ void sp_segment(const BfCtx& c, u32x4 (&fr)[S::D], f32x16 (&acc)[2], const u32x4* inA_hi, const u32x4* inA_mid,
+                                           const u32x4* inB_hi, const u32x4* inB_mid, Epi&& epi, PrevEpi&& prev_epi) {
+  constexpr int KS = KSA + KSB;
+  static_assert(KS > BF_EPI_POS + 1, "segment too short for the deferred epilogue");
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  static_for<NFT * KS>([&](auto I) {
+    constexpr int f = I / KS, ks = I % KS, i0 = 2 * (S0 + I), i1 = i0 + 1;
+    constexpr int cur = (P0 + f) & 1, oth = (P0 + f + 1) & 1;
+    if constexpr (i0 % BF_CHUNK == BF_SYNC_POS) bf_sync<S, i0 / BF_CHUNK>(c);
+    const u32x4 a_hi = fr[i0 % S::D];
+    if constexpr (i0 + S::D < S::NFRAG) fr[i0 % S::D] = bf_frag<S>(c, i0 + S::D);
+    const u32x4 a_mid = fr[i1 % S::D];
+    if constexpr (i1 + S::D < S::NFRAG) fr[i1 % S::D] = bf_frag<S>(c, i1 + S::D);
+    const u32x4& b_hi = ks < KSA ? inA_hi[ks < KSA ? ks : 0] : inB_hi[ks < KSA ? 0 : ks - KSA];
+    const u32x4& b_mid = ks < KSA ? inA_mid[ks < KSA ? ks : 0] : inB_mid[ks < KSA ? 0 : ks - KSA];
+    acc[cur] = bf_mfma(a_mid, b_hi, acc[cur]);
+    acc[cur] = bf_mfma(a_hi, b_mid, acc[cur]);
+    acc[cur] = bf_mfma(a_hi, b_hi, acc[cur]);
+    if constexpr (ks == BF_EPI_POS) {
+      if constexpr (f == 0)
+        prev_epi(acc[oth]);
+      else
+        epi(f - 1, acc[oth]);
+      if constexpr (f + 1 < NFT)
+        acc[oth] = BT0 >= 0 ? bf_bias_tile(c, BT0 + f + 1) : zero;
+      else if constexpr (NEXT_BT >= 0)
+        acc[oth] = bf_bias_tile(c, NEXT_BT);
+      else
+        acc[oth] = zero;
+    }
+  });
+}
+
+__global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  using S = SplitStream;
+  BfCtx c;
+  c.wimg = a.wbf;
+  c.lds = lds;
+  c.lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
+  c.lane = threadIdx.x & 63;
+  c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = c.lane, j = lane & 31, h = lane >> 5;
+  const int m = blockIdx.x * (SP_WG / 2) + c.wv * 32 + j;
+  const bool valid = m < a.M;
+  const int mc = valid ? m : a.M - 1;
+  const int ray = mc / a.N;
+
+  // ---- ordinary loads first (drained before anything else is in flight)
+  const float* rf = a.rayf + (size_t)ray * RAYF;
+  float p[3], dw[3];
+  sample_point(rf, a.t[mc], p);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dw[i] = rf[RF_DWRD + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p[i]), "+v"(dw[i]));
+
+  bf_stream_start<S>(c);
+
+  // ---- positional encodings (fp32, as in the exact path) straight into two-part B operands:
+  // k-step ks, slot pair (s, s+1): features k = 16ks + 4h + {0,1 | 2,3 | 8,9 | 10,11} = (sin, cos) pairs pi = 8ks + 2h + {0, 1, 4, 5}
+  u32x4 gp_hi[4], gp_mid[4], gd_hi[2], gd_mid[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pi = 8 * ks + 2 * h + (q & 1) + 4 * (q >> 1);
+      float sv = 0.f, cv = 0.f;
+      if (pi < 30) {
+        const int cc = pi / 10, l = pi - 10 * cc;
+        const float x = (cc == 0) ? p[0] : ((cc == 1) ? p[1] : p[2]);
+        sincos_phase(x * __uint_as_float(kFreqPointBits[l]), sv, cv);
+      }
+      const HiMid e = split2(sv, cv);
+      gp_hi[ks][q] = e.hi;
+      gp_mid[ks][q] = e.mid;
+    }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pi = 8 * ks + 2 * h + (q & 1) + 4 * (q >> 1);
+      float sv = 0.f, cv = 0.f;
+      if (pi < 12) {
+        const int cc = pi / 4, l = pi - 4 * cc;
+        const float x = (cc == 0) ? dw[0] : ((cc == 1) ? dw[1] : dw[2]);
+        sincos_phase(x * __uint_as_float(kFreqDirBits[l]), sv, cv);
+      }
+      const HiMid e = split2(sv, cv);
+      gd_hi[ks][q] = e.hi;
+      gd_mid[ks][q] = e.mid;
+    }
+
+  u32x4 fr[S::D];
+  bf_stream_first<S>(c, fr);
+
+  u32x4 Xh[16], Xm[16], Yh[16], Ym[16];
+  f32x16 acc[2];
+  acc[0] = bf_bias_tile(c, BFB_L0);
+  // epilogue of a ReLU layer: tile f (fp32 accumulators) -> ReLU -> two-part packed k-steps 2f, 2f+1 of the next layer's input
+  auto relu_to = [&](u32x4* oh, u32x4* om) {
+    return [oh, om](int f, const f32x16& A) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const HiMid e = split2(fmaxf(A[8 * mh + 2 * q], 0.f), fmaxf(A[8 * mh + 2 * q + 1], 0.f));
+          oh[2 * f + mh][q] = e.hi;
+          om[2 * f + mh][q] = e.mid;
+        }
+    };
+  };
+  auto last_of = [](auto epi, int f) { return [epi, f](const f32x16& A) { epi(f, A); }; };
+  auto nothing = [](const f32x16&) {};
+  auto nothing_f = [](int, const f32x16&) {};
+
+  // ---- layers 0..7 (nerf.py:104-112)
+  sp_segment<S, BFS_L0, 8, 4, 0, BFB_L0, 0, BFB_L0 + 8>(c, fr, acc, gp_hi, gp_mid, nullptr, nullptr, relu_to(Xh, Xm), nothing);
+  sp_segment<S, BFS_L1, 8, 16, 0, BFB_L0 + 8, 0, BFB_L0 + 16>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
+  sp_segment<S, BFS_L1 + 128, 8, 16, 0, BFB_L0 + 16, 0, BFB_L0 + 24>(c, fr, acc, Yh, Ym, nullptr, nullptr, relu_to(Xh, Xm), last_of(relu_to(Yh, Ym), 7));
+  sp_segment<S, BFS_L1 + 256, 8, 16, 0, BFB_L0 + 24, 0, BFB_L0 + 32>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
+  sp_segment<S, BFS_L4, 8, 16, 4, BFB_L0 + 32, 0, BFB_L0 + 40>(c, fr, acc, Yh, Ym, gp_hi, gp_mid, relu_to(Xh, Xm), last_of(relu_to(Yh, Ym), 7));
+  sp_segment<S, BFS_L5, 8, 16, 0, BFB_L0 + 40, 0, BFB_L0 + 48>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
+  sp_segment<S, BFS_L5 + 128, 8, 16, 0, BFB_L0 + 48, 0, BFB_L0 + 56>(c, fr, acc, Yh, Ym, nullptr, nullptr, relu_to(Xh, Xm), last_of(relu_to(Yh, Ym), 7));
+  sp_segment<S, BFS_L5 + 256, 8, 16, 0, BFB_L0 + 56, 0, BFB_SIGMA>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
+  // ---- sigma head (one tile, row 0) on h7: sigma = |w_sigma . h7 + b|  (nerf.py:94, 113-115)
+  float spre = 0.f;
+  auto sig_epi = [&](const f32x16& A) { spre = A[0]; };
+  sp_segment<S, BFS_SIG, 1, 16, 0, BFB_SIGMA, 0, BFB_DIR>(c, fr, acc, Yh, Ym, nullptr, nullptr, nothing_f, last_of(relu_to(Yh, Ym), 7));
+  // ---- point_info folded into dir_info: c = relu(W_dir[:, :24] gamma_d + W_fold h7 + b_dir + W_dir[:, 24:] b_pi)  (nerf.py:117-118)
+  sp_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd_hi, gd_mid, Yh, Ym, relu_to(Xh, Xm), sig_epi);
+  if (valid && h == 0) a.sigma[m] = fabsf(spre);
+  // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
+  sp_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, Xh, Xm, nullptr, nullptr, nothing_f, last_of(relu_to(Xh, Xm), 3));
+  if (valid && h == 0) {
+    a.rgb[(size_t)m * 3 + 0] = 1.0f / (1.0f + expf(-acc[1][0]));
+    a.rgb[(size_t)m * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
+    a.rgb[(size_t)m * 3 + 2] = 1.0f / (1.0f + expf(-acc[1][2]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight image: bias block (fp32, the bf16 image's), then for every step s of the bf16 layout the hi fragment and the mid fragment
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_weights_split(const Weights24 w, const float* __restrict__ fold, unsigned char* __restrict__ img) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid < BF_NFRAG * 64) {
+    const int step = gid >> 6, lane = gid & 63, i = lane & 31, h = lane >> 5;
+    u32x4 vh, vm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = 4 * h + 2 * (q & 1) + 8 * (q >> 1);
+      const HiMid e = split2(bf_weight(w, fold, step, i, kk, h), bf_weight(w, fold, step, i, kk + 1, h));
+      vh[q] = e.hi;
+      vm[q] = e.mid;
+    }
+    unsigned char* dst = img + BF_BIAS_BYTES + (size_t)(2 * step) * BF_FRAG_BYTES + lane * 16;
+    *reinterpret_cast<u32x4*>(dst) = vh;
+    *reinterpret_cast<u32x4*>(dst + BF_FRAG_BYTES) = vm;
+  } else {
+    const int b = gid - BF_NFRAG * 64;
+    if (b < BF_BIAS_BYTES / 4) {
+      const int tile = b >> 5, i = b & 31;
+      reinterpret_cast<float*>(img)[b] = tile < BF_NBIAS_TILES ? bf_bias(w, fold, tile, i) : 0.f;
+    }
+  }
+}
+
+size_t split_image_bytes() { return (size_t)BF_BIAS_BYTES + (size_t)SP_NFRAG * BF_FRAG_BYTES; }
+
+hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st) {
+  const int threads = BF_NFRAG * 64 + BF_BIAS_BYTES / 4;
+  hipLaunchKernelGGL(k_pack_weights_split, dim3((threads + 255) / 256), dim3(256), 0, st, w, fold, img);
+  return hipGetLastError();
+}
+
+hipError_t launch_field_fwd_split(const FieldArgs& a, hipStream_t st) {
+  static std::atomic<unsigned long long> opted{0};
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_split)}, BF_LDS_BYTES)) return e;
+  const int wgs = (a.M + SP_WG / 2 - 1) / (SP_WG / 2);
+  hipLaunchKernelGGL(k_field_fwd_split, dim3(wgs), dim3(SP_WG), BF_LDS_BYTES, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace nerf

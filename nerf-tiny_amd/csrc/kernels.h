@@ -114,6 +114,10 @@ hipError_t launch_pack_weights_bf16(const Weights24& w, const float* fold, unsig
 hipError_t launch_pack_bias_block_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st);  // inference, 16x16x32 MFMA form
 hipError_t launch_pack_weights_bf16x(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
+// split-fp32 inference (field_fwd_split.hip): fp32 operands as two bf16 parts, three bf16 MFMAs per product
+size_t split_image_bytes();
+hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
+hipError_t launch_field_fwd_split(const FieldArgs& a, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
 hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st);
 size_t merge_lds_bytes(int P);

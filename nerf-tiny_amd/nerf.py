@@ -76,8 +76,10 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, model, need_grad, row, col, pb, K9, ray0, *params):
         B = row.shape[0]
         Nc, Nf = model.num_coarse, model.num_fine
+        bf16 = getattr(model, "bf16_mlp", False)
         flags = ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
-                 | (_abi.BF16_MLP if getattr(model, "bf16_mlp", False) else 0))
+                 | (_abi.BF16_MLP if bf16 else 0)
+                 | (_abi.SPLIT_MLP if getattr(model, "split_mlp", False) and not need_grad and not bf16 else 0))  # inference only
         ws = model._workspace(B, flags)
         # rendering loops (`with model.frozen_weights():`): the packed weight image a previous call of the SAME frozen section
         # left in this workspace is reused.  Outside such a section the image is rebuilt on every call (12 us): a version
@@ -159,6 +161,10 @@ class NeRFModel(nn.Module):
         self.force_tile_kernel = False
         #: BASELINE.json cfg3: run the MLP on bf16 MFMA (fp32 accumulation, fp32 everything else); ~1e-2 of the fp32 result
         self.bf16_mlp = False
+        #: INFERENCE calls (no grad) only: evaluate the fp32 MLP on bf16 MFMA with every fp32 operand split into two bf16 parts (hi + mid)
+        #: and three MFMAs per product, fp32 accumulation -- inside the same 1e-4 bar as the exact-fp32 default,
+        #: 3x faster.  Off by default: the default keeps exact k-ordered fp32 fma chains; training forwards ignore it
+        self.split_mlp = False
         #: parallel.GradBucket or None.  When set (read when the forward records the graph), backward writes the 24 gradients straight
         #: into the bucket's flat buffer and makes p.grad its views (overwrite semantics: one backward per step, a second one before
         #: the gradients were consumed raises; autograd.grad / hooks unsupported), so the all-reduce needs no pack / unpack
@@ -220,6 +226,7 @@ class NeRFModel(nn.Module):
     def __setstate__(self, d):  # checkpoints written by an earlier build lack the newer plumbing attributes
         super().__setstate__(d)
         self.__dict__.setdefault("grad_bucket", None)
+        self.__dict__.setdefault("split_mlp", False)
         self.__dict__["_ws"], self.__dict__["_ws_generation"] = {}, {}
         self.__dict__["_last_ws"], self.__dict__["_packed"], self.__dict__["_frozen"] = None, set(), False
 

@@ -15,6 +15,7 @@ row, col, pb, K, Ct = bench.synth_inputs(0)
 m = bench.synth_weights(0).to(dev)
 row, col, pb, Ct = row.to(dev), col.to(dev), pb.float().to(dev), Ct.to(dev)
 m.bf16_mlp = os.environ.get('BF16') == '1'
+m.split_mlp = os.environ.get('SPLIT') == '1'
 train = os.environ.get('TRAIN') == '1'
 
 
