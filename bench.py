@@ -206,12 +206,19 @@ PMC_FILES = {(False, False): "pmc_latest.json", (True, False): "pmc_train_latest
              (True, True): "pmc_bf16_train_latest.json"}  # (train, bf16) -> committed summary under profiles/
 
 
+PMC_SPLIT_FILE = "pmc_split_fwd_latest.json"
+
+
+def pmc_file(leg):
+    return PMC_SPLIT_FILE if getattr(leg, "split", False) else PMC_FILES[(leg.train, leg.bf16)]
+
+
 def read_traffic(leg, kernel_keys, scale=None):
     """HBM bytes per launch from the committed rocprofv3 --pmc summaries (scripts/collect_profiles_r03.sh + scripts/summarize_pmc.py:
     separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction): the mean over `kernel_keys`
     (per-kernel averages over their launches), or with `scale` = {key: launches per step} their sum per step.
     Not measured in this run: the block says so in `traffic_source`."""
-    p = os.path.join(ROOT, "profiles", PMC_FILES[(leg.train, leg.bf16)])
+    p = os.path.join(ROOT, "profiles", pmc_file(leg))
     try:
         with open(p) as f:
             d = json.load(f)
@@ -225,8 +232,8 @@ def read_traffic(leg, kernel_keys, scale=None):
 # one timed leg
 # --------------------------------------------------------------------------------------------------------------------
 class Leg:
-    def __init__(self, name, train, bf16):
-        self.name, self.train, self.bf16 = name, train, bf16
+    def __init__(self, name, train, bf16, split=False):
+        self.name, self.train, self.bf16, self.split = name, train, bf16, split  # split: the opt-in split-fp32 inference mode (model.split_mlp)
 
 
 def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
@@ -238,6 +245,7 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
 
     row, col, pb, C_true = inputs
     model.bf16_mlp = leg.bf16
+    model.split_mlp = leg.split
     model.grad_bucket = bucket if leg.train else None
     ar_events = []
 
@@ -285,13 +293,14 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
         elapsed = float(t.item())
     ar_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)) if ar_events else None
     model.grad_bucket = None
+    model.split_mlp = False
     return elapsed, prof, ar_ms
 
 
 def rooflines(leg, prof, b_local, steps):
     """Roofline blocks of one leg from the library's HIP events (recorded on the stream the kernels run on)."""
     peak = PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS
-    src = "profiles/" + PMC_FILES[(leg.train, leg.bf16)] + " (committed rocprofv3 --pmc passes of this leg; not re-measured in this run)"
+    src = "profiles/" + pmc_file(leg) + " (committed rocprofv3 --pmc passes of this leg; not re-measured in this run)"
 
     def scaled(t):  # the PMC passes ran at 4096 rays per step; a smaller batch of this run moves proportionally less (the slabs aside)
         return None if t is None else int(t * b_local / B)
@@ -309,6 +318,24 @@ def rooflines(leg, prof, b_local, steps):
     # average launch, so that rocprofv3's per-kernel average is directly comparable.  `achieved` counts the ALGORITHMIC FLOPs of the
     # reference's network (1,182,976 per sample); the kernels EXECUTE 8/9 of them: point_info is folded into dir_info
     # (one 128 x 256 layer instead of 256 x 256 + 128 x 256) -- `executed_flop_frac` says so.
+    if getattr(leg, "split", False):
+        # split-fp32 inference: the fp32 MLP on the bf16 pipe, THREE bf16 MFMAs (hi*hi, hi*mid, mid*hi) per fp32 product.  Roofline = the
+        # bf16 MFMA peak against the bf16 FLOPs the kernel executes (3 x the executed fp32 ones); the algorithmic fp32 figure beside it
+        ms = sum(prof.get(k, (0.0, 0))[0] for k in ("field_fwd_coarse", "field_fwd_fine"))
+        n = sum(prof.get(k, (0.0, 0))[1] for k in ("field_fwd_coarse", "field_fwd_fine"))
+        avg = ms / max(n, 1)
+        alg = FLOP_PER_SAMPLE * b_local * (NC + NF) // 2
+        exe = 3 * EXEC_FLOP_PER_SAMPLE * b_local * (NC + NF) // 2
+        ach = exe / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+        blk = {"bound": "mfma (bf16 pipe)", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+               "traffic": scaled(read_traffic(leg, ["k_field_fwd_split"])), "traffic_source": src,
+               "kernel": "k_field_fwd_split (average of the coarse- and fine-pass launches)", "avg_launch_ms": round(avg, 4), "launches": n,
+               "flop_per_launch": exe, "achieved_algorithmic_fp32": round(alg / (avg * 1e-3) / 1e12, 2) if avg > 0 else 0.0,
+               "algorithmic_over_fp32_mfma_peak": round(alg / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3) if avg > 0 else 0.0,
+               "note": "achieved = executed bf16 MFMA FLOPs (3 per fp32 product of the folded network) against the dense bf16 peak; "
+                       "achieved_algorithmic_fp32 = the reference network's fp32 FLOPs (SURVEY.md 8d) per second, above the fp32 MFMA peak because "
+                       "the products run on the bf16 pipe with 16-bit-mantissa operands (parity: `parity.split_mlp_vs_reference`)"}
+        return blk, None
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
     fwd_key = (["k_field_fwd_bf16<true>"] if leg.train else ["k_field_fwd_bf16x"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
     fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
@@ -384,11 +411,12 @@ def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong)
     flop_ray = FLOP_PER_RAY_TRAIN if leg.train else FLOP_PER_RAY_FWD
     roof, phases = rooflines(leg, prof, b_local, steps)
     rep = {"metric": "rays/sec (64 coarse + 128 fine samples), lego 400x400" + (" [train step: fwd+loss+bwd]" if leg.train else "")
-                     + (" [cfg3: bf16 MLP / fp32 composite]" if leg.bf16 else ""),
+                     + (" [cfg3: bf16 MLP / fp32 composite]" if leg.bf16 else "")
+                     + (" [split-fp32 inference: fp32 operands as bf16 hi + mid, 3 bf16 MFMAs per product, fp32 accumulate; same 1e-4 bar]" if getattr(leg, "split", False) else ""),
            "value": round(value, 1), "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
-           "dtype": "bf16" if leg.bf16 else "f32", "roofline": roof,
+           "dtype": "bf16" if leg.bf16 else ("f32 (bf16 hi+mid split operands, fp32 accumulate)" if getattr(leg, "split", False) else "f32"), "roofline": roof,
            "whole_path_tflops_per_gpu": round(value / world * flop_ray / 1e12, 2),
-           "whole_path_frac_of_mfma_peak": round(value / world * flop_ray / 1e12 / (PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS), 4),
+           "whole_path_frac_of_mfma_peak": round(value / world * flop_ray / 1e12 / (PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS), 4),  # (split leg: of the FP32 peak, i.e. > 1)
            "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in prof.items()}}
     if phases is not None:
         rep["roofline_phases"] = phases
@@ -433,12 +461,17 @@ def parity_block(model, dev):
            "bar": "max_rel <= 1e-4 (fp32)"}
     with torch.no_grad():
         out.update(errs(*m(row, col, pbd, K)))
+        m.split_mlp = True   # the opt-in split-fp32 inference mode: held to the same bar
+        out["split_mlp_vs_reference"] = errs(*m(row, col, pbd, K))
+        m.split_mlp = False
         m.bf16_mlp = True
         out["bf16_mlp_vs_fp32_reference"] = errs(*m(row, col, pbd, K))
     out["pass"] = bool(out["max_rel_C_coarse"] <= 1e-4 and out["max_rel_C_fine"] <= 1e-4)
+    out["split_mlp_vs_reference"]["pass"] = bool(out["split_mlp_vs_reference"]["max_rel_C_coarse"] <= 1e-4 and out["split_mlp_vs_reference"]["max_rel_C_fine"] <= 1e-4)
     for k in ("max_rel_C_coarse", "max_rel_C_fine", "max_elementwise_rel_C_fine"):
         out[k] = float(f"{out[k]:.3e}")
-        out["bf16_mlp_vs_fp32_reference"][k] = float(f"{out['bf16_mlp_vs_fp32_reference'][k]:.3e}")
+        for sub in ("bf16_mlp_vs_fp32_reference", "split_mlp_vs_reference"):
+            out[sub][k] = float(f"{out[sub][k]:.3e}")
     return out
 
 
@@ -484,6 +517,9 @@ def main():
                     help="weak (default, the driver's contract): every rank renders its own 4096-ray batches; strong: ONE 4096-ray "
                          "batch is split into contiguous slices of 4096/N rays (SURVEY.md 8d cfg3), with the global ray 0's (near, far) "
                          "handed to every rank (quirk Q6)")
+    ap.add_argument("--split", action="store_true",
+                    help="forward only: the opt-in split-fp32 inference mode (model.split_mlp) as the leg of the line (profiling runs; NOT the "
+                         "driver's headline, which stays the exact-fp32 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the leg named by --mode/--mlp (profiling runs)")
     ap.add_argument("--dry", action="store_true", help="CPU rehearsal of the launcher + process group over gloo (no kernels; tests only)")
@@ -553,16 +589,20 @@ def main():
         b_local = B // world
     inputs = shard(full, rank * b_local, (rank + 1) * b_local) if strong else shard(full, 0, B)
 
-    head = Leg("headline", args.mode == "train", args.mlp == "bf16")
+    if args.split and (args.mode == "train" or args.mlp == "bf16"):
+        raise SystemExit("--split is the fp32 inference mode: not with --mode train / --mlp bf16")
+    head = Leg("headline", args.mode == "train", args.mlp == "bf16", args.split)
     elapsed, prof, ar_ms = run_leg(head, model, inputs, K, args.steps, args.warmup, dist, dev, bucket)
     rep = leg_report(head, elapsed, prof, ar_ms, args.steps, args.warmup, world, b_local, strong)
     extra = {}
-    legs = (("forward_f32", False, False, 20, 3), ("train_f32", True, False, 8, 2), ("forward_bf16", False, True, 50, 5), ("train_bf16", True, True, 20, 3))
+    legs = (("forward_f32", False, False, 20, 3), ("train_f32", True, False, 8, 2), ("forward_bf16", False, True, 50, 5), ("train_bf16", True, True, 20, 3),
+            ("forward_f32_split", False, False, 40, 4))
     if not args.no_extra:
         for name, train, bf16, k, w in legs:
-            if (train, bf16) == (head.train, head.bf16):
+            split = name.endswith("_split")
+            if (train, bf16, split) == (head.train, head.bf16, head.split):
                 continue
-            leg = Leg(name, train, bf16)
+            leg = Leg(name, train, bf16, split)
             e, p, a = run_leg(leg, model, inputs, K, k, w, dist, dev, bucket)
             extra[name] = leg_report(leg, e, p, a, k, w, world, b_local, strong)
 
@@ -579,7 +619,7 @@ def main():
         bs = B // world
         s_in = shard(g_full, rank * bs, (rank + 1) * bs)
         for name, train, bf16, k, w in legs:
-            leg = Leg(name, train, bf16)
+            leg = Leg(name, train, bf16, name.endswith("_split"))
             e, p, a = run_leg(leg, model, s_in, K, 3 * k, w + 2, dist, dev, bucket)
             extra["strong_" + name] = brief(leg_report(leg, e, p, a, 3 * k, w + 2, world, bs, True), B)
         inputs = shard(full, 0, B)
@@ -589,12 +629,13 @@ def main():
     proxy = None
     if world == 1 and dist is None and not strong and not args.no_extra:
         proxy = {}
-        t_full = {name: (rep["ms_per_step"] if (train, bf16) == (head.train, head.bf16) else extra[name]["ms_per_step"]) for name, train, bf16, _, _ in legs}
+        t_full = {name: (rep["ms_per_step"] if (train, bf16, name.endswith("_split")) == (head.train, head.bf16, head.split) else extra[name]["ms_per_step"])
+                  for name, train, bf16, _, _ in legs}
         for bs in (512, 400):
             s_in = shard(full, 0, bs)
             proxy[str(bs)] = {}
             for name, train, bf16, k, w in legs:
-                leg = Leg(name, train, bf16)
+                leg = Leg(name, train, bf16, name.endswith("_split"))
                 kk = 4 * k
                 e, p, a = run_leg(leg, model, s_in, K, kk, w + 3, dist, dev, bucket)
                 proxy[str(bs)][name] = brief(leg_report(leg, e, p, a, kk, w + 3, 1, bs, True), bs)

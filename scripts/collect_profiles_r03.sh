@@ -10,7 +10,7 @@ mkdir -p $OUT $ROOT/gpurun_out/pmc
 cd $ROOT
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err && echo "bench (default line) done"
 cd /tmp && export TMPDIR=/tmp
-for leg in "fwd_f32:--mode forward --mlp f32 --steps 20 --warmup 3" "train_f32:--mode train --mlp f32 --steps 6 --warmup 2" "fwd_bf16:--mode forward --mlp bf16 --steps 40 --warmup 5" "train_bf16:--mode train --mlp bf16 --steps 10 --warmup 3"; do
+for leg in "fwd_f32:--mode forward --mlp f32 --steps 20 --warmup 3" "train_f32:--mode train --mlp f32 --steps 6 --warmup 2" "fwd_bf16:--mode forward --mlp bf16 --steps 40 --warmup 5" "train_bf16:--mode train --mlp bf16 --steps 10 --warmup 3" "split_fwd:--mode forward --split --steps 30 --warmup 4"; do
   name=${leg%%:*}; args=${leg#*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $name -- python3 $ROOT/bench.py $args --no-cpu-baseline --no-extra > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_rocprof.err && echo "rocprof stats $name done"
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_COEXEC_CYCLES"; do

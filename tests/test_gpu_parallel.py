@@ -43,7 +43,8 @@ def test_bench_train_leg_with_rccl_allreduce():
     assert out["allreduce_ms"] is not None and 0.0 < out["allreduce_ms"] < 50.0
     assert set(out["roofline_phases"]) == {"forward_with_saves", "dx_chain", "dw"}
     # the weak legs and -- the code path of the driver's N = 8 line -- the strong-scaling form of all four legs (here: one rank = the whole batch)
-    assert set(out["extra"]) == {"forward_f32", "forward_bf16", "train_bf16", "strong_forward_f32", "strong_train_f32", "strong_forward_bf16", "strong_train_bf16"}
+    assert set(out["extra"]) == {"forward_f32", "forward_bf16", "train_bf16", "forward_f32_split", "strong_forward_f32", "strong_train_f32", "strong_forward_bf16",
+                                 "strong_train_bf16", "strong_forward_f32_split"}
     for name, leg in out["extra"].items():
         if name.startswith("strong_"):
             assert leg["value"] > 0 and leg["rays_per_step"] == 4096 and 0.0 < leg["roofline_frac"] < 1.125  # (algorithmic FLOPs: 9/8 of the executed ones)
@@ -51,4 +52,4 @@ def test_bench_train_leg_with_rccl_allreduce():
             assert leg["value"] > 0 and 0.0 < leg["roofline"]["frac"] < 1.125 and leg["roofline"].get("frac_executed", 0.0) < 1.0
     assert out["extra"]["train_bf16"]["allreduce_ms"] is not None
     assert out["extra"]["strong_train_f32"]["allreduce_ms"] is not None and out["extra"]["strong_train_bf16"]["allreduce_ms"] is not None
-    assert out["parity"]["pass"] is True
+    assert out["parity"]["pass"] is True and out["parity"]["split_mlp_vs_reference"]["pass"] is True
