@@ -44,16 +44,34 @@ __device__ __forceinline__ HiMid split2(float x0, float x1) {
 }
 
 // One segment: NFT output tiles x (KSA + KSB) k-steps starting at STEP S0 (fragments 2 S0 ..); inputs inA (k-steps 0..KSA-1) then
-// inB, each as hi / mid parts.  Per step three MFMAs, the small products first.  Accumulator hand-over as in bf_segment.
+// inB, each as hi / mid parts.  Per step three MFMAs, the small products first.  Accumulator hand-over as in bf_segment, except that
+// the epilogue of the finished tile is SPREAD: with one wave per SIMD nothing else fills the matrix pipe while this wave converts, so the
+// 8 register pairs of a tile (epi(f, part, acc): ~13 vector instructions each) go one per k-step behind k-steps 2 .. 9 of the next
+// tile -- about four vector instructions per MFMA, which the 32-cycle MFMA hides -- instead of ~110 in one lump.  Segments shorter than
+// ten k-steps keep the lump.
+struct EpiTmp { float x0, x1; unsigned hi; };  // state of one register pair between the three phases of its conversion
+
 template <class S, int S0, int NFT, int KSA, int KSB, int BT0, int P0, int NEXT_BT, class Epi, class PrevEpi>
 __device__ __forceinline__ void sp_segment(const BfCtx& c, u32x4 (&fr)[S::D], f32x16 (&acc)[2], const u32x4* inA_hi, const u32x4* inA_mid,
                                            const u32x4* inB_hi, const u32x4* inB_mid, Epi&& epi, PrevEpi&& prev_epi) {
   constexpr int KS = KSA + KSB;
-  static_assert(KS > BF_EPI_POS + 1, "segment too short for the deferred epilogue");
+  constexpr bool SPREAD = KS >= BF_EPI_POS + 8;
+  constexpr int LAST = SPREAD ? BF_EPI_POS + 7 : BF_EPI_POS;  // k-step behind which the finished accumulator is free again
+  static_assert(KS > LAST, "segment too short for the deferred epilogue");
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  EpiTmp tmp = {0.f, 0.f, 0u};
   static_for<NFT * KS>([&](auto I) {
     constexpr int f = I / KS, ks = I % KS, i0 = 2 * (S0 + I), i1 = i0 + 1;
     constexpr int cur = (P0 + f) & 1, oth = (P0 + f + 1) & 1;
+    constexpr bool EPI = SPREAD && ks >= BF_EPI_POS && ks <= LAST;
+    auto phase = [&](auto PH) {  // one third of the conversion of register pair ks - BF_EPI_POS of the finished tile, behind ONE MFMA
+      if constexpr (EPI) {
+        if constexpr (f == 0)
+          prev_epi(ks - BF_EPI_POS, (int)PH, acc[oth], tmp);
+        else
+          epi(f - 1, ks - BF_EPI_POS, (int)PH, acc[oth], tmp);
+      }
+    };
     if constexpr (i0 % BF_CHUNK == BF_SYNC_POS) bf_sync<S, i0 / BF_CHUNK>(c);
     const u32x4 a_hi = fr[i0 % S::D];
     if constexpr (i0 + S::D < S::NFRAG) fr[i0 % S::D] = bf_frag<S>(c, i0 + S::D);
@@ -61,14 +79,28 @@ __device__ __forceinline__ void sp_segment(const BfCtx& c, u32x4 (&fr)[S::D], f3
     if constexpr (i1 + S::D < S::NFRAG) fr[i1 % S::D] = bf_frag<S>(c, i1 + S::D);
     const u32x4& b_hi = ks < KSA ? inA_hi[ks < KSA ? ks : 0] : inB_hi[ks < KSA ? 0 : ks - KSA];
     const u32x4& b_mid = ks < KSA ? inA_mid[ks < KSA ? ks : 0] : inB_mid[ks < KSA ? 0 : ks - KSA];
+    // program order = issue order for one wave per SIMD: every MFMA is followed by its share of vector work, and the fences keep
+    // the compiler from collecting that work into lumps the matrix pipe would have to wait for
     acc[cur] = bf_mfma(a_mid, b_hi, acc[cur]);
+    phase(std::integral_constant<int, 0>{});
+    if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);
     acc[cur] = bf_mfma(a_hi, b_mid, acc[cur]);
+    phase(std::integral_constant<int, 1>{});
+    if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);
     acc[cur] = bf_mfma(a_hi, b_hi, acc[cur]);
-    if constexpr (ks == BF_EPI_POS) {
-      if constexpr (f == 0)
-        prev_epi(acc[oth]);
-      else
-        epi(f - 1, acc[oth]);
+    phase(std::integral_constant<int, 2>{});
+    if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!SPREAD && ks == BF_EPI_POS) {
+      static_for<8>([&](auto P) {
+        static_for<3>([&](auto PH) {
+          if constexpr (f == 0)
+            prev_epi((int)P, (int)PH, acc[oth], tmp);
+          else
+            epi(f - 1, (int)P, (int)PH, acc[oth], tmp);
+        });
+      });
+    }
+    if constexpr (ks == LAST) {
       if constexpr (f + 1 < NFT)
         acc[oth] = BT0 >= 0 ? bf_bias_tile(c, BT0 + f + 1) : zero;
       else if constexpr (NEXT_BT >= 0)
@@ -145,22 +177,27 @@ __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a)
   u32x4 Xh[16], Xm[16], Yh[16], Ym[16];
   f32x16 acc[2];
   acc[0] = bf_bias_tile(c, BFB_L0);
-  // epilogue of a ReLU layer: tile f (fp32 accumulators) -> ReLU -> two-part packed k-steps 2f, 2f+1 of the next layer's input
+  // epilogue of a ReLU layer, one register pair group at a time: part = (mh, q) of tile f (fp32 accumulators) -> ReLU (one integer max
+  // per value: the fp32 bit pattern of max(x, 0)) -> two-part packed slot q of k-step 2f + mh of the next layer's input
   auto relu_to = [&](u32x4* oh, u32x4* om) {
-    return [oh, om](int f, const f32x16& A) {
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const HiMid e = split2(fmaxf(A[8 * mh + 2 * q], 0.f), fmaxf(A[8 * mh + 2 * q + 1], 0.f));
-          oh[2 * f + mh][q] = e.hi;
-          om[2 * f + mh][q] = e.mid;
-        }
+    return [oh, om](int f, int part, int ph, const f32x16& A, EpiTmp& t) {
+      const int mh = part >> 2, q = part & 3;
+      if (ph == 0) {  // ReLU (integer max on the fp32 bit patterns), hi parts
+        t.x0 = __int_as_float(max(__float_as_int(A[8 * mh + 2 * q]), 0));
+        t.x1 = __int_as_float(max(__float_as_int(A[8 * mh + 2 * q + 1]), 0));
+        t.hi = pack2(t.x0, t.x1);
+        oh[2 * f + mh][q] = t.hi;
+      } else if (ph == 1) {  // residuals
+        t.x0 -= __uint_as_float(t.hi << 16);
+        t.x1 -= __uint_as_float(t.hi & 0xffff0000u);
+      } else {  // mid parts
+        om[2 * f + mh][q] = pack2(t.x0, t.x1);
+      }
     };
   };
-  auto last_of = [](auto epi, int f) { return [epi, f](const f32x16& A) { epi(f, A); }; };
-  auto nothing = [](const f32x16&) {};
-  auto nothing_f = [](int, const f32x16&) {};
+  auto last_of = [](auto epi, int f) { return [epi, f](int part, int ph, const f32x16& A, EpiTmp& t) { epi(f, part, ph, A, t); }; };
+  auto nothing = [](int, int, const f32x16&, EpiTmp&) {};
+  auto nothing_f = [](int, int, int, const f32x16&, EpiTmp&) {};
 
   // ---- layers 0..7 (nerf.py:104-112)
   sp_segment<S, BFS_L0, 8, 4, 0, BFB_L0, 0, BFB_L0 + 8>(c, fr, acc, gp_hi, gp_mid, nullptr, nullptr, relu_to(Xh, Xm), nothing);
@@ -173,7 +210,7 @@ __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a)
   sp_segment<S, BFS_L5 + 256, 8, 16, 0, BFB_L0 + 56, 0, BFB_SIGMA>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
   // ---- sigma head (one tile, row 0) on h7: sigma = |w_sigma . h7 + b|  (nerf.py:94, 113-115)
   float spre = 0.f;
-  auto sig_epi = [&](const f32x16& A) { spre = A[0]; };
+  auto sig_epi = [&](int part, int ph, const f32x16& A, EpiTmp&) { if (part == 0 && ph == 0) spre = A[0]; };
   sp_segment<S, BFS_SIG, 1, 16, 0, BFB_SIGMA, 0, BFB_DIR>(c, fr, acc, Yh, Ym, nullptr, nullptr, nothing_f, last_of(relu_to(Yh, Ym), 7));
   // ---- point_info folded into dir_info: c = relu(W_dir[:, :24] gamma_d + W_fold h7 + b_dir + W_dir[:, 24:] b_pi)  (nerf.py:117-118)
   sp_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd_hi, gd_mid, Yh, Ym, relu_to(Xh, Xm), sig_epi);

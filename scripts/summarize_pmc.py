@@ -22,7 +22,7 @@ for k, cs in acc.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]:
         d["mfma_busy_over_sq_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CYCLES"]
     key = k
-    if "k_field_fwd" in k and "bf16" not in k and "<true" not in k:  # the dominant kernel of bench.py's headline leg (inference instantiation)
+    if ("k_field_fwd_reg" in k or k.startswith("k_field_fwd<")) and "<true" not in k:  # the dominant kernel of bench.py's headline leg (inference instantiation)
         key = "k_field_fwd"
     out[key] = d
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
