@@ -399,9 +399,9 @@ def rooflines(leg, prof, b_local, steps):
 DW_LAUNCHES = {"k_dw4<4, false>": 7, "k_dw4<4, true>": 1, "k_dw4<2, false>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_fold_grads": 1,
                "k_dir_prep": 1, "k_dir_gamma_part": 1, "k_dir_gamma_final": 1}
 # bf16-MLP variant (dw_bf16.hip): layer 0, the six 256 x 256 products in one launch, layer 4, the folded product with the sigma head,
-# the colour head, their reduces, the fold's gradient kernel
+# the colour head, ONE launch for all slab sums, the fold's gradient kernel
 DW_BF16_LAUNCHES = {"k_dw_bf16<2, false>": 1, "k_dw_bf16<8, false>": 1, "k_dw_bf16<10, false>": 1, "k_dw_bf16<9, true>": 1,
-                    "k_dw_bf16<4, false>": 1, "k_dw_bf16_reduce": 13, "k_fold_grads": 1}
+                    "k_dw_bf16<4, false>": 1, "k_dw_bf16_reduce_batch": 1, "k_fold_grads": 1}
 DW_BF16_KIB_PER_WAVE_BLOCK = 280  # G and X pieces of bf16_common.h over the products (142 + 138 KiB)
 
 
