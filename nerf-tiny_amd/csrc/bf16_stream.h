@@ -85,15 +85,6 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_d
                : "memory");
 }
 
-// the same with the non-temporal hint (once-read streams: the weight-gradient kernels' operands)
-__device__ __forceinline__ void glds16_nt(const unsigned char* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
 // A 16-byte store of a saved piece (layer inputs, ReLU masks, pre-activation gradients: written once, read once by a later kernel,
 // gigabytes per step) with the non-temporal hint: measured 3 % on the whole bf16 train step against plain stores (forward-with-saves
 // 0.93 -> 0.87 ms, chains 0.96 -> 0.91, and the weight-gradient kernels that follow 1.45 -> 1.38: less dirty data parked in L2).

@@ -121,11 +121,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
         src = a.Z + ((size_t)wb * 2 + ks) * BF_FRAG_BYTES;
       }
       const int h = lane >> 5, s = (lane & 31) ^ (4 * (2 * (ks & 1) + h));
-#ifdef NERF_NT_DW_LOADS  // (timing experiment)
-      glds16_nt(src + (h * 32 + s) * 16, lds_base + slot * Geo::SLOT_BYTES + dst * BF_FRAG_BYTES);
-#else
-      glds16(src + (h * 32 + s) * 16, lds_base + slot * Geo::SLOT_BYTES + dst * BF_FRAG_BYTES);
-#endif
+      glds16(src + (h * 32 + s) * 16, lds_base + slot * Geo::SLOT_BYTES + dst * BF_FRAG_BYTES);  // (the non-temporal form measured the same)
     }
   };
   if (nb > 0) {
