@@ -37,6 +37,10 @@ def test_ws_bytes_and_errors(pkg):
     with pytest.raises(pkg._abi.NerfHipError, match="2\\^31"):
         pkg._abi.ws_bytes(2_000_000, 1024, 1024, pkg._abi.SAVE_FOR_BACKWARD)
     assert pkg._abi.ws_bytes(1_000_000, 64, 128, 0) > 0
+    # the opt-in split-fp32 inference mode brings its own packed image (2.1 MB) and nothing else; with the bf16 flag it is ignored
+    d = pkg._abi.ws_bytes(4096, 64, 128, pkg._abi.SPLIT_MLP) - n0
+    assert 2_100_000 < d < 2_300_000
+    assert pkg._abi.ws_bytes(4096, 64, 128, pkg._abi.SPLIT_MLP | pkg._abi.BF16_MLP) == pkg._abi.ws_bytes(4096, 64, 128, pkg._abi.BF16_MLP)
 
 
 def test_no_cpu_fallback(pkg):
