@@ -104,6 +104,13 @@ def test_parity_on_trained_weights(oracle, pkg, dev):
     ec, ef = max_rel(Cc, oc), max_rel(Cf, of)
     print(f"trained weights: max-rel C_coarse {ec:.2e} C_fine {ef:.2e}")
     assert ec < 1e-4 and ef < 1e-4
+    # the opt-in split-fp32 inference mode is held to the same bar on trained weights
+    m.split_mlp = True
+    with torch.no_grad():
+        Sc, Sf = m(row, col, pb, run.K_inv)
+    sc, sf = max_rel(Sc, oc), max_rel(Sf, of)
+    print(f"trained weights, split-fp32 inference: max-rel C_coarse {sc:.2e} C_fine {sf:.2e}")
+    assert sc < 1e-4 and sf < 1e-4
 
 
 def test_gather_rays_matches_reference_loader_tuples(pkg, dev, tmp_path):
