@@ -23,6 +23,8 @@ if __name__ == "__main__":
     ap.add_argument("--synthetic", action="store_true", help="procedural scene instead of IMG_DIR")
     ap.add_argument("--total-iter", type=int, default=None)
     ap.add_argument("--bf16-mlp", action="store_true", help="run the MLP on bf16 MFMA (cfg3; also ini key BF16_MLP = True)")
+    ap.add_argument("--split-mlp", action="store_true", help="render (validation, display) on the split-fp32 inference kernels: same 1e-4 bar, "
+                                                             "3x the rate; training is unaffected (also ini key SPLIT_MLP = True)")
     args = ap.parse_args()
     conf = ConfigParser()
     conf.read(os.path.join(args.conf_dir, args.conf + ".ini"))
@@ -36,6 +38,7 @@ if __name__ == "__main__":
         scene = P.data.synthetic_scene(n_pic=8, H=64, W=64)
         kw["datasets"] = {"train": scene, "val": scene, "test": scene}
     kw["bf16_mlp"] = args.bf16_mlp or ast.literal_eval(c("BF16_MLP", "False"))
+    kw["split_mlp"] = args.split_mlp or ast.literal_eval(c("SPLIT_MLP", "False"))
     run = P.NeRFRunner(**kw)
     run.trainer("train")
     run.display()

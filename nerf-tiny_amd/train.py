@@ -90,12 +90,13 @@ class NeRFRunner:
     """The reference's runner surface: same 17 constructor arguments (nerf.py:354-372), ``trainer(mode)`` (nerf.py:445)
     and ``display()`` (nerf.py:503).  ``mode`` defaults to "train" so the reference's ``main.py:55`` call works.
     Extra keyword-only arguments: ``datasets`` (dict mode -> dataset, to run without files), ``log_every`` (host sync
-    period; the reference syncs every iteration), ``bf16_mlp`` (BASELINE.json cfg3: the MLP on bf16 MFMA, default off)."""
+    period; the reference syncs every iteration), ``bf16_mlp`` (BASELINE.json cfg3: the MLP on bf16 MFMA, default off), ``split_mlp`` (rendering calls -- validation,
+    ``display()`` -- on the split-fp32 inference kernels: same 1e-4 bar, 3x the rate; training forwards ignore it; default off)."""
 
     def __init__(self, gpu=0, img_dir="../nerf_synthetic/lego/", results_path="./results/", ckpt_path="./checkpoint/", low_res=1,
                  total_iter=100000, batch_ray=400, learning=1e-3, lr_gamma=0.1, lr_milestone=(10, 200), n_coarse=64, n_fine=128,
                  data_type="sync", step=100, decay_end=200000, sched="EXP", continue_=False, *, datasets=None, log_every=None,
-                 seed=624, bf16_mlp=False):
+                 seed=624, bf16_mlp=False, split_mlp=False):
         from . import nerf as _nerf
 
         if not torch.cuda.is_available():
@@ -121,6 +122,7 @@ class NeRFRunner:
             self.model = torch.load(last_ckpt, weights_only=False).to(self.device)
         self.last_iter = last_iter
         self.model.bf16_mlp = bool(bf16_mlp)  # an attribute, not part of the checkpoint format: set after a resume too
+        self.model.split_mlp = bool(split_mlp)
 
         def ds(mode):
             if datasets is not None:
