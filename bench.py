@@ -370,7 +370,7 @@ def rooflines(leg, prof, b_local, steps):
         ach = flop / (dw_ms * 1e-3) / 1e12 if dw_ms > 0 else 0.0
         dw = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
               "traffic": dw_traffic, "traffic_source": dw_src,
-              "kernel": "k_dw4 / k_dw_thin / k_dw_reduce / k_fold_grads / k_dir_* (all weight-gradient products of one step incl. the reduce and the thin colour head = one 'launch')",
+              "kernel": "k_dw4_group / k_dw4 / k_dw_thin / k_dw_reduce / k_fold_grads / k_dir_* (all weight-gradient products of one step incl. the reduce and the thin colour head = one 'launch')",
               "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "flop_per_launch": flop}
     # executed / algorithmic FLOPs of the other two phases (the fold removes 65,536 MACs per sample from each: DESIGN.md 3a)
     chain_exec = 1.0 - 2 * 65536 * (NC + NF) / (CHAIN_FLOP_COARSE * NC + CHAIN_FLOP_FINE * NF)
@@ -393,10 +393,10 @@ def rooflines(leg, prof, b_local, steps):
     return dominant, phases
 
 
-# launches of the fp32 weight-gradient phase per train step (dw_f32.hip): the 128 x 128-block products (layers 1-7), the folded
+# launches of the fp32 weight-gradient phase per train step (dw_f32.hip): the seven 128 x 128-block products (layers 1-7) in ONE launch, the folded
 # dpre_dir^T h7 product that carries the sigma head (k_dw4<4, true>), the 128 x 64-block ones (layer 0, layer 4's skip columns), the
 # colour head, the reduce, the fold's gradient kernel and the three small kernels of dir_info's direction-encoding columns
-DW_LAUNCHES = {"k_dw4<4, false>": 7, "k_dw4<4, true>": 1, "k_dw4<2, false>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_fold_grads": 1,
+DW_LAUNCHES = {"k_dw4_group": 1, "k_dw4<4, true>": 1, "k_dw4<2, false>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_fold_grads": 1,
                "k_dir_prep": 1, "k_dir_gamma_part": 1, "k_dir_gamma_final": 1}
 # bf16-MLP variant (dw_bf16.hip): layer 0, the six 256 x 256 products in one launch, layer 4, the folded product with the sigma head,
 # the colour head, ONE launch for all slab sums, the fold's gradient kernel

@@ -59,7 +59,8 @@ size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 // head, + the thin colour head -- in launch order, with their slab offsets; pointers are filled in by nerf_hip_backward (null
 // here: only sizes matter for the layout).
 constexpr int DW_EARLY_ITEMS = 9;  // layers 1..7, layer 4's skip columns, layer 0 = every tensor of point_layer[0..7]
-long long build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw, float* mbuf) {
+long long build_dw_batch(DwBatch& b, const float* G, const float* save, const float* dz4, size_t MS, float* const* dw, float* mbuf,
+                         bool grouped = true) {
   memset(&b, 0, sizeof(b));
   auto add = [&](const float* g, int nout, const float* x, int nin, int nin_real, float* dW, int ldw, int col0, float* db) -> DwItem& {
     DwItem& it = b.item[b.n++];
@@ -80,11 +81,12 @@ long long build_dw_batch(DwBatch& b, const float* G, const float* save, const fl
   mi.has_sig = 1; mi.sig = dz4 ? dz4 + 3 : nullptr; mi.dW2 = D(W_SIGMA);
   DwItem& th = add(dz4, 32, St(S_C), 128, 128, D(W_COLOR), HALF, 0, D(B_COLOR));                 // colour head (X = c) + the bias gradients of both heads
   th.thin = 1; th.db2 = D(B_SIGMA);
-  // Every product gets ALL DW_WGS workgroups in a launch of its own.  (One launch for all products, the CUs dealt out in
-  // proportion to their MFMA time, was built and measured in round 2: no gain.  See DESIGN.md section 4b.)
+  // The seven 256 x 256 products share one launch with DW_GROUP_WGS workgroups each (dw_f32.hip: k_dw4_group); every other product
+  // gets ALL DW_WGS workgroups in a launch of its own.
+  b.grouped = grouped ? 7 : 0;
   long long off = 0;
   for (int i = 0; i < b.n; ++i) {
-    b.item[i].nwg = DW_WGS;
+    b.item[i].nwg = i < b.grouped ? DW_GROUP_WGS : DW_WGS;
     b.item[i].wg0 = 0;
     b.item[i].slab_off = off; off += (long long)dw_item_slab_floats(b.item[i]);
   }
@@ -542,7 +544,7 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
   } else {
     ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
     DwBatch batch;
-    build_dw_batch(batch, G, save, at<float>(ws, L.dz), MS, dw, at<float>(ws, L.mbuf));
+    build_dw_batch(batch, G, save, at<float>(ws, L.dz), MS, dw, at<float>(ws, L.mbuf), Mtot <= DW_GROUP_MAX_ROWS);
     float* slabs = at<float>(ws, L.slabs);
     batch.slabs = slabs;
 #ifdef NERF_STAMPS

@@ -1,6 +1,6 @@
 // dw_f32.hip -- the weight-gradient GEMMs of the fp32 train step for MI355X (gfx950).
 //
-//  k_dw4<NCB>     one launch per product: dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM
+//  k_dw4<NCB>     one product: dW[out][in] = sum_m G[m][out] * X[m][in] as a split-M fp32 MFMA GEMM
 //                 (v_mfma_f32_32x32x2_f32 with the SAMPLE as the k index): both operands are read straight from their
 //                 row-major HBM images (lane (q, h) <- columns 4q..4q+3 of G and NCB q.. of X, row m + h).  ONE wave per SIMD:
 //                 a 128 x 32 NCB output block = 64 NCB accumulators per wave, 4 waves = one workgroup per CU on 1/256 of the
@@ -8,6 +8,7 @@
 //                 SIMD's fp32 lanes, so every VALU instruction in the loop is MFMA time lost: a wave carries at most one extra
 //                 duty -- the column sums of its G block (bias gradient) or, on the point_info product, the sigma head's weight
 //                 gradient (sum_m dsigma_pre[m] * h7[m][:], same X) -- as asm-pinned adds / FMAs in the same loop.
+//  k_dw4_group    the seven 256 x 256 products (layers 1..7) in ONE launch, 36 workgroups each: same body, a seventh of the slabs
 //  k_dw_thin      the colour head as one thin product: A = the [rows][4] buffer (dz_r, dz_g, dz_b, dsigma_pre), one 32-row
 //                 output tile per wave, X = c; the column sums of A are the bias gradients of both heads.  HBM-bound.
 //  k_dw_reduce    ONE launch per step: sums the slabs of all products in a fixed order (deterministic, no float atomics)
@@ -402,9 +403,9 @@ __global__ __launch_bounds__(512, 2) void k_dw_thin(const DwItem p, const long l
 // MIXED: the 128 x 256 product that carries the sigma head AND column sums on every wave (DW_SIG_*): a kernel of its own, so that the
 // loops of the other products keep the schedule they were tuned with (this compiler schedules the stage loads of a loop differently
 // when other loops share its kernel).
-template <int NCB, bool MIXED = false>
-__global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
-  const int lane = threadIdx.x & 63, lw = blockIdx.x;
+template <int NCB, bool MIXED>
+__device__ __forceinline__ void dw4_body(const DwItem& p, const long long Mtot, float* __restrict__ slabs, const int lw) {
+  const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef NERF_STAMPS
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
@@ -439,9 +440,12 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
   const float* sbase = p.sig;
   const unsigned goff = (unsigned)(h * WIDTH + 4 * q) * 4u, xoff = (unsigned)(h * WIDTH + NCB * q) * 4u, soff = (unsigned)h * 16u;
   const int duty = dwi_duty(p, bi, bj);  // wave-uniform
+  // a ragged range (the last workgroups of a launch): whole ring rounds through the pipelined loop, only the rest row pair by row pair
+  const int r_full = r_begin + (r_end - r_begin) / (2 * DW4_DEPTH) * (2 * DW4_DEPTH), r_stop = r_end;
   if constexpr (MIXED) {
     if (r_begin < r_end) {
-      if (r_nom <= Mrows) {
+      if (r_begin < r_full) {
+        const int r_end = r_full;
         const RayDuty rd{p.raysum, p.ray_nc, p.ray_nf, p.rows_c, p.rows_c / (p.ray_nc > 0 ? p.ray_nc : 1)};
         if (duty == DW_SIG_RAY_LO) {
           asm volatile("; sigma head + per-ray sums, low half" ::: "memory");
@@ -456,13 +460,13 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
           asm volatile("; sigma head + column sums, high half" ::: "memory");
           dw_stream<NCB, MIXED ? DW_SIG_BIAS_HI : DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum, rd, lane, ssum);
         }
-      } else {
-        dw_stream_tail<NCB>(gbase, xbase, sbase, goff, xoff, soff, h, r_begin, r_end, duty, acc, bsum, ssum);
       }
+      if (r_full < r_stop) dw_stream_tail<NCB>(gbase, xbase, sbase, goff, xoff, soff, h, r_full, r_stop, duty, acc, bsum, ssum);
     }
   } else
   if (r_begin < r_end) {
-    if (r_nom <= Mrows) {
+    if (r_begin < r_full) {
+      const int r_end = r_full;
       // (the empty asm statements differ on purpose: identical starts of the branches get hoisted into this block, and the
       // loops then wait for the whole ring at every k-step)
       if (duty == DW_BIAS) {
@@ -490,9 +494,8 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
         asm volatile("; no duty" ::: "memory");
         dw_stream<NCB, DW_PLAIN>(gbase, xbase, sbase, goff, xoff, soff, r_begin, r_end, acc, bsum);
       }
-    } else {
-      dw_stream_tail<NCB>(gbase, xbase, sbase, goff, xoff, soff, h, r_begin, r_end, duty, acc, bsum);
     }
+    if (r_full < r_stop) dw_stream_tail<NCB>(gbase, xbase, sbase, goff, xoff, soff, h, r_full, r_stop, duty, acc, bsum);
   }
   constexpr size_t wave_rows = (size_t)4 * NCB * 16;
   float* sl = slabs + p.slab_off;
@@ -531,9 +534,24 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
 #endif
 }
 
-// One launch per product, one small kernel per block shape (this compiler schedules the stage loads of a loop differently when
-// other loops share its kernel).  A single launch for all big products, the CUs dealt out in proportion to their MFMA time,
-// was also built and measured in round 2: no gain.
+template <int NCB, bool MIXED = false>
+__global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mtot, float* __restrict__ slabs) {
+  dw4_body<NCB, MIXED>(p, Mtot, slabs, blockIdx.x);
+}
+
+// The seven 256 x 256 products of a step (layers 1..7) in ONE launch, grid (workgroups per product, products): a product gets
+// DW_GROUP_WGS = 36 workgroups (7 x 36 = 252 of the 256 CUs, one round), each on 1/36 of the rows.  With a launch per product and a
+// workgroup per CU every product wrote and re-read 256 slabs of 256 KiB -- 0.9 GB per step whatever the batch: a quarter of this phase at
+// 512 rays (the reference's own regime is BATCH_RAY = 400); now a seventh of that, and six launch boundaries fewer.  Measured
+// (scripts/ab_dw_group.sh, phase time per step): 400 rays 0.92 -> 0.76 ms, 512: 1.07 -> 0.90, 1024: 1.79 -> 1.61, 4096: 6.15 -> 6.00.
+// (Round 2's "one launch for all products" measured no gain: its ragged last workgroup ran the row-pair loop over its whole range --
+// see r_full in dw4_body -- and hid the gain.)
+__global__ __launch_bounds__(256) void k_dw4_group(const DwBatch b, const long long Mtot, float* __restrict__ slabs) {
+  dw4_body<4, false>(b.item[blockIdx.y], Mtot, slabs, blockIdx.x);
+}
+
+// The other products: one launch each, one small kernel per block shape (this compiler schedules the stage loads of a loop
+// differently when other loops share its kernel).
 // Sums the slabs of every product of the step and scatters into the nn.Linear-layout gradients: grid (blocks, items).
 // Weight blocks: 256 consecutive slab elements per block, thread = (4 consecutive elements, a quarter of the slabs) with four
 // 16-byte loads in flight, the quarters combined through LDS in a fixed order (deterministic, no float atomics).  The blocks
@@ -701,6 +719,13 @@ hipError_t launch_fold_grads(const FoldGradArgs& a, hipStream_t st) {
 
 hipError_t launch_dw(const DwBatch& b, long long Mtot, float* slabs, hipStream_t st, int first, int count) {
   const int last = count < 0 ? b.n : first + count;
+  if (b.grouped > 0 && first == 0) {  // (a range that starts inside the group is not something api.hip asks for)
+    if (last < b.grouped) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dw4_group, dim3(b.item[0].nwg, b.grouped), dim3(256), 0, st, b, Mtot, slabs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    first = b.grouped;
+  }
   for (int i = first; i < last; ++i) {
     const DwItem& p = b.item[i];
     if (p.thin) hipLaunchKernelGGL(k_dw_thin, dim3(p.nwg), dim3(512), 0, st, p, Mtot, slabs);

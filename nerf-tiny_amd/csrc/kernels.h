@@ -181,9 +181,20 @@ struct DwItem {
 };
 constexpr int DW_WGS = 256;  // workgroups of the launch: one per CU, dealt out over the products
 constexpr int DW_MAX_ITEMS = 13;
+// The seven 256 x 256 products share ONE launch (dw_f32.hip: k_dw4_group), DW_GROUP_WGS workgroups each.  The macros are for A/B builds
+// (make variant DEFS=-DNERF_DW_GROUP_MAX_ROWS=0: a launch per product, as up to round 2).
+#ifndef NERF_DW_GROUP_WGS
+#define NERF_DW_GROUP_WGS 36
+#endif
+#ifndef NERF_DW_GROUP_MAX_ROWS
+#define NERF_DW_GROUP_MAX_ROWS (1ll << 40)
+#endif
+constexpr int DW_GROUP_WGS = NERF_DW_GROUP_WGS;
+constexpr long long DW_GROUP_MAX_ROWS = NERF_DW_GROUP_MAX_ROWS;  // rows of G (rays x (Nc + Nf)) up to which the products are grouped
 struct DwBatch {
   DwItem item[DW_MAX_ITEMS];
   int n;
+  int grouped;             // > 0: items [0, grouped) are 256 x 256 products of equal nwg that share ONE launch (k_dw4_group)
   const float* slabs;
 };
 
