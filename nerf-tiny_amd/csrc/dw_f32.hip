@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void k_dw4(const DwItem p, const long long Mto
 // DW_GROUP_WGS = 36 workgroups (7 x 36 = 252 of the 256 CUs, one round), each on 1/36 of the rows.  With a launch per product and a
 // workgroup per CU every product wrote and re-read 256 slabs of 256 KiB -- 0.9 GB per step whatever the batch: a quarter of this phase at
 // 512 rays (the reference's own regime is BATCH_RAY = 400); now a seventh of that, and six launch boundaries fewer.  Measured
-// (scripts/ab_dw_group.sh, phase time per step): 400 rays 0.92 -> 0.76 ms, 512: 1.07 -> 0.90, 1024: 1.79 -> 1.61, 4096: 6.15 -> 6.00.
+// (scripts/ab_variants.sh, phase time per step): 400 rays 0.92 -> 0.76 ms, 512: 1.07 -> 0.90, 1024: 1.79 -> 1.61, 4096: 6.15 -> 6.00.
 // (Round 2's "one launch for all products" measured no gain: its ragged last workgroup ran the row-pair loop over its whole range --
 // see r_full in dw4_body -- and hid the gain.)
 __global__ __launch_bounds__(256) void k_dw4_group(const DwBatch b, const long long Mtot, float* __restrict__ slabs) {

@@ -45,8 +45,15 @@ struct BxStream {
   static constexpr int PROLOGUE_STORES = 0;
   __device__ static constexpr int stores_before(int) { return 0; }
 };
+// The two-column form (NH = 4): ONE wave per SIMD holds 64 samples (four 16-sample groups, 512 registers), 4 waves = the same 256
+// samples per workgroup and per pass over the weight image, but every fragment read from LDS feeds FOUR MFMAs instead of two.
+struct BxStream4 : BxStream {
+  static constexpr int PW = 4;  // 16 pieces of a chunk over 4 waves
+};
+template <int NH> struct BxStreamOf { using type = BxStream; };
+template <> struct BxStreamOf<4> { using type = BxStream4; };
 
-struct Acc2 { f32x4 c[2]; };  // one 16-feature tile for the two 16-sample halves
+template <int NH> struct AccN { f32x4 c[NH]; };  // one 16-feature tile for the wave's NH 16-sample groups
 
 __device__ __forceinline__ f32x4 bx_mfma(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -56,18 +63,18 @@ __device__ __forceinline__ f32x4 bx_mfma(const u32x4& a, const u32x4& b, const f
 // acc[(P0 + f) & 1]; the finished accumulators of tile f-1 are consumed by epi(f-1, .) right after the second k-step of tile
 // f (prev_epi: the last tile of the previous segment) and re-started at the bias of tile f+1 (bias float offset B0 + 16 f;
 // NEXT_B: of the next segment's tile 0, < 0: none).
-template <int S0, int NT, int KSA, int KSB, int B0, int P0, int NEXT_B, class Epi, class PrevEpi>
-__device__ __forceinline__ void bx_segment(const BfCtx& c, u32x4 (&fr)[BF_D], Acc2 (&acc)[2], const u32x4 (*inA)[8], const u32x4 (*inB)[8],
+template <int NH, int S0, int NT, int KSA, int KSB, int B0, int P0, int NEXT_B, class Epi, class PrevEpi>
+__device__ __forceinline__ void bx_segment(const BfCtx& c, u32x4 (&fr)[BF_D], AccN<NH> (&acc)[2], const u32x4 (*inA)[8], const u32x4 (*inB)[8],
                                            Epi&& epi, PrevEpi&& prev_epi) {
-  using S = BxStream;
+  using S = typename BxStreamOf<NH>::type;
   constexpr int KS = KSA + KSB;
   static_assert(KS >= 2, "segment too short for the deferred epilogue");
   const int q = c.lane >> 4;
   auto bias = [&](int off) {
     const float4 v = *reinterpret_cast<const float4*>(c.lds + (off + 4 * q) * 4);
-    Acc2 a;
-    a.c[0] = f32x4{v.x, v.y, v.z, v.w};
-    a.c[1] = a.c[0];
+    AccN<NH> a;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) a.c[h] = f32x4{v.x, v.y, v.z, v.w};
     return a;
   };
   static_for<NT * KS>([&](auto I) {
@@ -77,7 +84,7 @@ __device__ __forceinline__ void bx_segment(const BfCtx& c, u32x4 (&fr)[BF_D], Ac
     const u32x4 a = fr[idx % S::D];
     if constexpr (idx + S::D < S::NFRAG) fr[idx % S::D] = bf_frag<S>(c, idx + S::D);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       if constexpr (ks < KSA)
         acc[cur].c[h] = bx_mfma(a, inA[h][ks], acc[cur].c[h]);
       else
@@ -96,9 +103,11 @@ __device__ __forceinline__ void bx_segment(const BfCtx& c, u32x4 (&fr)[BF_D], Ac
   });
 }
 
-__global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a) {
+template <int NH>
+__global__ __launch_bounds__(1024 / NH, 1) void k_field_fwd_bf16x(const FieldArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  using S = BxStream;
+  using S = typename BxStreamOf<NH>::type;
+  using Acc = AccN<NH>;
   BfCtx c;
   c.wimg = a.wbf;
   c.lds = lds;
@@ -106,14 +115,14 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
   c.lane = threadIdx.x & 63;
   c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = c.lane, n = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * (BF_WG / 2) + c.wv * 32;
+  const int m0 = blockIdx.x * 256 + c.wv * (16 * NH);
 
-  // ---- ordinary loads first: this lane's two samples (n and 16 + n of the wave's 32)
-  int ms[2];
-  bool valid[2];
-  float p[2][3], dw[2][3];
+  // ---- ordinary loads first: this lane's NH samples (n, 16 + n, ... of the wave's 16 NH)
+  int ms[NH];
+  bool valid[NH];
+  float p[NH][3], dw[NH][3];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NH; ++h) {
     ms[h] = m0 + 16 * h + n;
     valid[h] = ms[h] < a.M;
     const int mc = valid[h] ? ms[h] : a.M - 1;
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
     for (int i = 0; i < 3; ++i) dw[h][i] = rf[RF_DWRD + i];
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p[h][i]), "+v"(dw[h][i]));
 
@@ -131,9 +140,9 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
 
   // ---- encodings straight into B-operand registers: k-step s, slot pair (j, j+1) = (sin, cos) pair
   // pi = 16s + 8 (j >> 2) + 2q + ((j >> 1) & 1), i.e. features 32s + 16 (j >> 2) + 4q + (j & 3)
-  u32x4 gp[2][8], gd[2][8];  // only [.][0..1] / [.][0] are used (the segment interface indexes [half][k-step])
+  u32x4 gp[NH][8], gd[NH][8];  // only [.][0..1] / [.][0] are used (the segment interface indexes [group][k-step])
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NH; ++h) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -162,72 +171,72 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16x(const FieldArgs a)
 
   // the direction encodings are needed 1,100 fragments later: parked in the 16 KiB of LDS behind the ring (32 bytes per lane)
   // instead of 8 registers the allocator would spill to scratch
-  u32x4* const gd_park = reinterpret_cast<u32x4*>(lds + BF_LDS_BYTES) + 2 * threadIdx.x;
-  gd_park[0] = gd[0][0];
-  gd_park[1] = gd[1][0];
+  u32x4* const gd_park = reinterpret_cast<u32x4*>(lds + BF_LDS_BYTES) + NH * threadIdx.x;
+#pragma unroll
+  for (int h = 0; h < NH; ++h) gd_park[h] = gd[h][0];
 
   u32x4 fr[BF_D];
   bf_stream_first<S>(c, fr);
 
-  u32x4 X[2][8], Y[2][8];
-  Acc2 acc[2];
+  u32x4 X[NH][8], Y[NH][8];
+  Acc acc[2];
   {
     const float4 v = *reinterpret_cast<const float4*>(lds + (4 * q) * 4);
-    acc[0].c[0] = f32x4{v.x, v.y, v.z, v.w};
-    acc[0].c[1] = acc[0].c[0];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) acc[0].c[h] = f32x4{v.x, v.y, v.z, v.w};
   }
   // epilogue of a ReLU layer: tile f (16 features) -> slots 2 (f & 1), 2 (f & 1) + 1 of k-step f >> 1 of the next layer
   auto relu_to = [&](u32x4 (*out)[8]) {
-    return [out](int f, const Acc2& A) {
+    return [out](int f, const Acc& A) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NH; ++h) {
         out[h][f >> 1][2 * (f & 1) + 0] = pack2_relu(A.c[h][0], A.c[h][1]);
         out[h][f >> 1][2 * (f & 1) + 1] = pack2_relu(A.c[h][2], A.c[h][3]);
       }
     };
   };
-  auto last_of = [](auto epi, int f) { return [epi, f](const Acc2& A) { epi(f, A); }; };
-  auto nothing = [](const Acc2&) {};
-  auto nothing_f = [](int, const Acc2&) {};
+  auto last_of = [](auto epi, int f) { return [epi, f](const Acc& A) { epi(f, A); }; };
+  auto nothing = [](const Acc&) {};
+  auto nothing_f = [](int, const Acc&) {};
 
   // ---- layers 0..7 (nerf.py:104-112)
-  bx_segment<BXS_L0, 16, 2, 0, 0 * 256, 0, 1 * 256>(c, fr, acc, gp, nullptr, relu_to(X), nothing);
-  bx_segment<BXS_L1, 16, 8, 0, 1 * 256, 0, 2 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
-  bx_segment<BXS_L1 + 128, 16, 8, 0, 2 * 256, 0, 3 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
-  bx_segment<BXS_L1 + 256, 16, 8, 0, 3 * 256, 0, 4 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
-  bx_segment<BXS_L4, 16, 8, 2, 4 * 256, 0, 5 * 256>(c, fr, acc, Y, gp, relu_to(X), last_of(relu_to(Y), 15));
-  bx_segment<BXS_L5, 16, 8, 0, 5 * 256, 0, 6 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
-  bx_segment<BXS_L5 + 128, 16, 8, 0, 6 * 256, 0, 7 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
-  bx_segment<BXS_L5 + 256, 16, 8, 0, 7 * 256, 0, BXB_SIGMA>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<NH, BXS_L0, 16, 2, 0, 0 * 256, 0, 1 * 256>(c, fr, acc, gp, nullptr, relu_to(X), nothing);
+  bx_segment<NH, BXS_L1, 16, 8, 0, 1 * 256, 0, 2 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<NH, BXS_L1 + 128, 16, 8, 0, 2 * 256, 0, 3 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<NH, BXS_L1 + 256, 16, 8, 0, 3 * 256, 0, 4 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<NH, BXS_L4, 16, 8, 2, 4 * 256, 0, 5 * 256>(c, fr, acc, Y, gp, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<NH, BXS_L5, 16, 8, 0, 5 * 256, 0, 6 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<NH, BXS_L5 + 128, 16, 8, 0, 6 * 256, 0, 7 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<NH, BXS_L5 + 256, 16, 8, 0, 7 * 256, 0, BXB_SIGMA>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
   // ---- sigma head (one tile, row 0) on h7  (nerf.py:94, 113-115)
-  float spre[2] = {0.f, 0.f};
-  auto sig_epi = [&](const Acc2& A) {
-    spre[0] = A.c[0][0];
-    spre[1] = A.c[1][0];
+  float spre[NH] = {};
+  auto sig_epi = [&](const Acc& A) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) spre[h] = A.c[h][0];
   };
-  bx_segment<BXS_SIG, 1, 8, 0, BXB_SIGMA, 0, BXB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 15));
+  bx_segment<NH, BXS_SIG, 1, 8, 0, BXB_SIGMA, 0, BXB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 15));
   // ---- point_info folded into dir_info: c = relu(W_dir[:, :24] gamma_d + W_fold h7 + bias) (nerf.py:117-118); its first tile also
   // retires the sigma tile
   {
     const int lane_d = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));  // (re-derived: no address register kept across the stream)
-    const u32x4* const back = reinterpret_cast<const u32x4*>(lds + BF_LDS_BYTES) + 2 * (c.wv * 64 + lane_d);
-    gd[0][0] = back[0];
-    gd[1][0] = back[1];
+    const u32x4* const back = reinterpret_cast<const u32x4*>(lds + BF_LDS_BYTES) + NH * (c.wv * 64 + lane_d);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) gd[h][0] = back[h];
   }
-  bx_segment<BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, Y, relu_to(X), sig_epi);
+  bx_segment<NH, BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, Y, relu_to(X), sig_epi);
   // (sample indices are re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing to keep alive or spill)
   const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int n_e = lane_e & 15;
   const bool q0_e = lane_e < 16;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NH; ++h) {
     const int me = m0 + 16 * h + n_e;
     if (me < a.M && q0_e) a.sigma[me] = fabsf(spre[h]);
   }
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
-  bx_segment<BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X), 7));
+  bx_segment<NH, BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X), 7));
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NH; ++h) {
     const int me = m0 + 16 * h + n_e;
     if (me < a.M && q0_e) {
 #pragma unroll
@@ -294,11 +303,15 @@ hipError_t launch_pack_weights_bf16x(const Weights24& w, const float* fold, unsi
   return hipGetLastError();
 }
 
+#ifndef NERF_BX_GROUPS  // 16-sample groups per wave: 2 = two waves per SIMD, 4 = the two-column form (make variant DEFS=-DNERF_BX_GROUPS=..)
+#define NERF_BX_GROUPS 2
+#endif
 hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st) {
   static std::atomic<unsigned long long> opted{0};
-  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16x)}, BX_LDS_BYTES)) return e;
-  const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
-  hipLaunchKernelGGL(k_field_fwd_bf16x, dim3(wgs), dim3(BF_WG), BX_LDS_BYTES, st, a);
+  constexpr int NH = NERF_BX_GROUPS;
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16x<NH>)}, BX_LDS_BYTES)) return e;
+  const int wgs = (a.M + 255) / 256;
+  hipLaunchKernelGGL(k_field_fwd_bf16x<NH>, dim3(wgs), dim3(1024 / NH), BX_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 
