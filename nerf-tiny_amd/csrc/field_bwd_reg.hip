@@ -188,7 +188,11 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
   const size_t MS = (size_t)a.MSrows * WIDTH;
   // this lane's row in the saved tensors / gradient buffers: lanes past the end of the pass own dump row Mtot + j (their
   // gradients are exact zeros -- dz = ds = 0 below -- so what they store is harmless and what they read only has to be finite)
+#ifdef NERF_TIMING_SAVE_ALIAS  // (timing experiments only: saved inputs read from / gradients written to the dump rows)
+  const long long rrow = a.Mtot + j;
+#else
   const long long rrow = valid ? (long long)(a.row0 + m) : a.Mtot + j;
+#endif
   const size_t grow_off = (size_t)rrow * WIDTH + 4 * h;  // this lane's 16-byte groups start here
   float* const grow = a.G + grow_off;
   const float* const srow = a.save + grow_off;

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
 
   // training: where this lane's rows / mask words go (rows of the coarse pass first, then the fine pass)
   const size_t MS = (size_t)a.MSrows * WIDTH;
+#ifdef NERF_TIMING_SAVE_ALIAS  // (timing experiments only: every save lands in the dump rows -> the stores issue, HBM sees none)
+  const long long rrow = a.Mtot + j;
+#else
   const long long rrow = valid ? (long long)(a.row0 + m) : a.Mtot + j;  // lanes past the end: dump row
+#endif
   float* const srow = SAVE ? a.save + (size_t)rrow * WIDTH + 4 * h : nullptr;
   uint16_t* const mrow = SAVE ? a.masks + ((size_t)(a.tile0 + (m0 >> 6)) * 4 + ((m0 >> 5) & 1)) * 256 + h * 32 + j : nullptr;
   const size_t MKS = (size_t)a.tiles_tot * 4 * 256;
