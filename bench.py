@@ -337,7 +337,7 @@ def rooflines(leg, prof, b_local, steps):
                        "the products run on the bf16 pipe with 16-bit-mantissa operands (parity: `parity.split_mlp_vs_reference`)"}
         return blk, None
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
-    fwd_key = (["k_field_fwd_bf16<true>"] if leg.train else ["k_field_fwd_bf16x"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
+    fwd_key = (["k_field_fwd_bf16<true>"] if leg.train else ["k_field_fwd_bf16x<2, 8>"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
     fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
                FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key)
     fwd["executed_flop_frac"] = round(EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE, 4)

@@ -36,6 +36,7 @@ static_assert((size_t)BF_BIAS_BYTES + (size_t)BX_NCHUNK * BF_CHUNK * BF_FRAG_BYT
 // bias block: the float layout of the 32x32x16 image (bf16_common.h), addressed per 16 features
 constexpr int BXB_SIGMA = 32 * BFB_SIGMA, BXB_DIR = 32 * BFB_DIR, BXB_COL = 32 * BFB_COL;
 
+constexpr int BX_SMALL_MAX_WGS = 256;  // 4-wave workgroups up to this many of them (one per CU)
 constexpr int BX_LDS_BYTES = BF_LDS_BYTES + BF_WG * 32;  // bias block + ring + 32 bytes per lane of parked encodings = 160 KiB
 static_assert(BX_LDS_BYTES <= 160 * 1024, "LDS of one CU");
 
@@ -50,7 +51,9 @@ struct BxStream {
 struct BxStream4 : BxStream {
   static constexpr int PW = 4;  // 16 pieces of a chunk over 4 waves
 };
-template <int NH> struct BxStreamOf { using type = BxStream; };
+// A 4-wave workgroup of the shipped form (NH = 2, WAVES = 4: 128 samples per workgroup) is what a SMALL pass gets: 32,768 coarse
+// samples (512 rays) are 128 workgroups of 256 samples -- half of the CUs idle -- or 256 of 128.
+template <int WAVES> struct BxStreamOf { using type = BxStream; };
 template <> struct BxStreamOf<4> { using type = BxStream4; };
 
 template <int NH> struct AccN { f32x4 c[NH]; };  // one 16-feature tile for the wave's NH 16-sample groups
@@ -63,10 +66,9 @@ __device__ __forceinline__ f32x4 bx_mfma(const u32x4& a, const u32x4& b, const f
 // acc[(P0 + f) & 1]; the finished accumulators of tile f-1 are consumed by epi(f-1, .) right after the second k-step of tile
 // f (prev_epi: the last tile of the previous segment) and re-started at the bias of tile f+1 (bias float offset B0 + 16 f;
 // NEXT_B: of the next segment's tile 0, < 0: none).
-template <int NH, int S0, int NT, int KSA, int KSB, int B0, int P0, int NEXT_B, class Epi, class PrevEpi>
+template <class S, int NH, int S0, int NT, int KSA, int KSB, int B0, int P0, int NEXT_B, class Epi, class PrevEpi>
 __device__ __forceinline__ void bx_segment(const BfCtx& c, u32x4 (&fr)[BF_D], AccN<NH> (&acc)[2], const u32x4 (*inA)[8], const u32x4 (*inB)[8],
                                            Epi&& epi, PrevEpi&& prev_epi) {
-  using S = typename BxStreamOf<NH>::type;
   constexpr int KS = KSA + KSB;
   static_assert(KS >= 2, "segment too short for the deferred epilogue");
   const int q = c.lane >> 4;
@@ -103,10 +105,10 @@ __device__ __forceinline__ void bx_segment(const BfCtx& c, u32x4 (&fr)[BF_D], Ac
   });
 }
 
-template <int NH>
-__global__ __launch_bounds__(1024 / NH, 1) void k_field_fwd_bf16x(const FieldArgs a) {
+template <int NH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16x(const FieldArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  using S = typename BxStreamOf<NH>::type;
+  using S = typename BxStreamOf<WAVES>::type;
   using Acc = AccN<NH>;
   BfCtx c;
   c.wimg = a.wbf;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(1024 / NH, 1) void k_field_fwd_bf16x(const FieldArg
   c.lane = threadIdx.x & 63;
   c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = c.lane, n = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * 256 + c.wv * (16 * NH);
+  const int m0 = blockIdx.x * (16 * NH * WAVES) + c.wv * (16 * NH);
 
   // ---- ordinary loads first: this lane's NH samples (n, 16 + n, ... of the wave's 16 NH)
   int ms[NH];
@@ -200,21 +202,21 @@ __global__ __launch_bounds__(1024 / NH, 1) void k_field_fwd_bf16x(const FieldArg
   auto nothing_f = [](int, const Acc&) {};
 
   // ---- layers 0..7 (nerf.py:104-112)
-  bx_segment<NH, BXS_L0, 16, 2, 0, 0 * 256, 0, 1 * 256>(c, fr, acc, gp, nullptr, relu_to(X), nothing);
-  bx_segment<NH, BXS_L1, 16, 8, 0, 1 * 256, 0, 2 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
-  bx_segment<NH, BXS_L1 + 128, 16, 8, 0, 2 * 256, 0, 3 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
-  bx_segment<NH, BXS_L1 + 256, 16, 8, 0, 3 * 256, 0, 4 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
-  bx_segment<NH, BXS_L4, 16, 8, 2, 4 * 256, 0, 5 * 256>(c, fr, acc, Y, gp, relu_to(X), last_of(relu_to(Y), 15));
-  bx_segment<NH, BXS_L5, 16, 8, 0, 5 * 256, 0, 6 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
-  bx_segment<NH, BXS_L5 + 128, 16, 8, 0, 6 * 256, 0, 7 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
-  bx_segment<NH, BXS_L5 + 256, 16, 8, 0, 7 * 256, 0, BXB_SIGMA>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<S, NH, BXS_L0, 16, 2, 0, 0 * 256, 0, 1 * 256>(c, fr, acc, gp, nullptr, relu_to(X), nothing);
+  bx_segment<S, NH, BXS_L1, 16, 8, 0, 1 * 256, 0, 2 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<S, NH, BXS_L1 + 128, 16, 8, 0, 2 * 256, 0, 3 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<S, NH, BXS_L1 + 256, 16, 8, 0, 3 * 256, 0, 4 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<S, NH, BXS_L4, 16, 8, 2, 4 * 256, 0, 5 * 256>(c, fr, acc, Y, gp, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<S, NH, BXS_L5, 16, 8, 0, 5 * 256, 0, 6 * 256>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
+  bx_segment<S, NH, BXS_L5 + 128, 16, 8, 0, 6 * 256, 0, 7 * 256>(c, fr, acc, Y, nullptr, relu_to(X), last_of(relu_to(Y), 15));
+  bx_segment<S, NH, BXS_L5 + 256, 16, 8, 0, 7 * 256, 0, BXB_SIGMA>(c, fr, acc, X, nullptr, relu_to(Y), last_of(relu_to(X), 15));
   // ---- sigma head (one tile, row 0) on h7  (nerf.py:94, 113-115)
   float spre[NH] = {};
   auto sig_epi = [&](const Acc& A) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) spre[h] = A.c[h][0];
   };
-  bx_segment<NH, BXS_SIG, 1, 8, 0, BXB_SIGMA, 0, BXB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 15));
+  bx_segment<S, NH, BXS_SIG, 1, 8, 0, BXB_SIGMA, 0, BXB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y), 15));
   // ---- point_info folded into dir_info: c = relu(W_dir[:, :24] gamma_d + W_fold h7 + bias) (nerf.py:117-118); its first tile also
   // retires the sigma tile
   {
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(1024 / NH, 1) void k_field_fwd_bf16x(const FieldArg
 #pragma unroll
     for (int h = 0; h < NH; ++h) gd[h][0] = back[h];
   }
-  bx_segment<NH, BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, Y, relu_to(X), sig_epi);
+  bx_segment<S, NH, BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, Y, relu_to(X), sig_epi);
   // (sample indices are re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing to keep alive or spill)
   const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int n_e = lane_e & 15;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(1024 / NH, 1) void k_field_fwd_bf16x(const FieldArg
     if (me < a.M && q0_e) a.sigma[me] = fabsf(spre[h]);
   }
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
-  bx_segment<NH, BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X), 7));
+  bx_segment<S, NH, BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X), 7));
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     const int me = m0 + 16 * h + n_e;
@@ -306,13 +308,24 @@ hipError_t launch_pack_weights_bf16x(const Weights24& w, const float* fold, unsi
 #ifndef NERF_BX_GROUPS  // 16-sample groups per wave: 2 = two waves per SIMD, 4 = the two-column form (make variant DEFS=-DNERF_BX_GROUPS=..)
 #define NERF_BX_GROUPS 2
 #endif
-hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st) {
+template <int NH, int WAVES>
+static hipError_t bx_launch(const FieldArgs& a, hipStream_t st) {
   static std::atomic<unsigned long long> opted{0};
-  constexpr int NH = NERF_BX_GROUPS;
-  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16x<NH>)}, BX_LDS_BYTES)) return e;
-  const int wgs = (a.M + 255) / 256;
-  hipLaunchKernelGGL(k_field_fwd_bf16x<NH>, dim3(wgs), dim3(1024 / NH), BX_LDS_BYTES, st, a);
+  constexpr int lds_bytes = BF_LDS_BYTES + 64 * WAVES * NH * 16, per_wg = 16 * NH * WAVES;
+  static_assert(lds_bytes <= BX_LDS_BYTES, "LDS of one CU");
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16x<NH, WAVES>)}, lds_bytes)) return e;
+  hipLaunchKernelGGL((k_field_fwd_bf16x<NH, WAVES>), dim3((a.M + per_wg - 1) / per_wg), dim3(64 * WAVES), lds_bytes, st, a);
   return hipGetLastError();
+}
+
+hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st) {
+  constexpr int NH = NERF_BX_GROUPS;
+  if constexpr (NH == 4) return bx_launch<4, 4>(a, st);
+#ifndef NERF_BX_NO_SMALL
+  // a pass of at most 256 x 128 samples: 4-wave workgroups, so that every CU gets one
+  if ((a.M + 127) / 128 <= BX_SMALL_MAX_WGS) return bx_launch<2, 4>(a, st);
+#endif
+  return bx_launch<2, 8>(a, st);
 }
 
 }  // namespace nerf

@@ -57,4 +57,4 @@ def test_train_traffic_lookup_matches_the_shipped_kernel_names():
     assert tb is not None and 4e9 < tb < 12e9, tb  # 7.6 GB per step measured (profiles/r03_train_bf16_pmc.json)
     for keys in (["k_field_fwd_bf16<true>"], ["k_field_bwd_bf16<true>", "k_field_bwd_bf16<false>"]):
         assert bench.read_traffic(bf_train, keys) is not None, keys
-    assert bench.read_traffic(bf_fwd, ["k_field_fwd_bf16x"]) is not None
+    assert bench.read_traffic(bf_fwd, ["k_field_fwd_bf16x<2, 8>"]) is not None
