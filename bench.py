@@ -405,6 +405,43 @@ DW_BF16_LAUNCHES = {"k_dw_bf16<2, false>": 1, "k_dw_bf16<8, false>": 1, "k_dw_bf
 DW_BF16_KIB_PER_WAVE_BLOCK = 280  # G and X pieces of bf16_common.h over the products (142 + 138 KiB)
 
 
+def frame_render_block(dev):
+    """The reference's display loop (nerf.py:503-520) on one 400 x 400 lego-like frame at the reference's own batch size (BATCH_RAY = 400,
+    conf/lego.ini:7): 400 batches of 400 rays in pixel order.  `per_batch` launches one batch per call, as the reference does;
+    `fused` is NeRFModel.render -- batches whose ray 0 has the same (near, far) share launches of up to 16,384 rays, every pixel the
+    same bits (tests/test_gpu_forward.py::test_render_fuses_batches_bit_identically).  Whole-frame wall time incl. the host side."""
+    import torch
+
+    import nerf_tiny_amd as P
+
+    H = W = 400
+    _, _, pb1, K, _ = synth_inputs(0, 1)
+    rr, cc = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    row, col = rr.reshape(-1).to(dev), cc.reshape(-1).to(dev)
+    pb = pb1.float().to(dev).expand(H * W, 17).contiguous()
+    m = synth_weights(0, sharp=True).to(dev)
+    bm = 400
+    m2 = P.NeRFModel(NC, NF, bm).to(dev)
+    m2.load_state_dict(m.state_dict())
+    out = {"frame": "400 x 400 lego-like view, pixel order, batch_ray 400 (the reference's conf/lego.ini), 64 + 128 samples", "rays": H * W}
+    for name, bf16, split in (("f32", False, False), ("f32_split", False, True), ("bf16", True, False)):
+        m2.bf16_mlp, m2.split_mlp = bf16, split
+        res = {}
+        for kind, fuse in (("per_batch", bm), ("fused", 16384)):
+            m2.render(row, col, pb, K, 0, 8 * bm, fuse_rays=fuse)  # warm-up (workspace, LDS opt-in)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            _, cf = m2.render(row, col, pb, K, fuse_rays=fuse)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            res[kind] = {"rays_per_s": round(H * W / dt, 1), "ms_per_frame": round(dt * 1e3, 2)}
+            res[kind + "_sum"] = float(cf.double().sum())
+        res["identical_pixels"] = res.pop("per_batch_sum") == res.pop("fused_sum")
+        res["speedup"] = round(res["fused"]["rays_per_s"] / res["per_batch"]["rays_per_s"], 2)
+        out[name] = res
+    return out
+
+
 def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong):
     rays = b_local * world * steps  # strong: b_local = B / world
     value = rays / elapsed
@@ -705,6 +742,11 @@ def main():
             out["parity"] = parity
         if extra:
             out["extra"] = extra
+        if world == 1 and not args.no_extra:
+            try:
+                out["frame_render"] = frame_render_block(dev)
+            except Exception as ex:
+                out["frame_render"] = {"error": str(ex)}
         if proxy is not None:
             out["per_rank_proxy"] = proxy
             out["implied_strong_scaling_8"] = proxy["implied_strong_scaling_8"]

@@ -71,16 +71,20 @@ class ResampleIndexError(RuntimeError):
     """Raised (when ``model.check_resample`` is on) where the reference prints a banner and exit(0)s (nerf.py:251-253)."""
 
 
+def _call_flags(model, need_grad: bool) -> int:
+    bf16 = getattr(model, "bf16_mlp", False)
+    return ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
+            | (_abi.BF16_MLP if bf16 else 0)
+            | (_abi.SPLIT_MLP if getattr(model, "split_mlp", False) and not need_grad and not bf16 else 0))  # inference only
+
+
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, need_grad, row, col, pb, K9, ray0, *params):
         B = row.shape[0]
         Nc, Nf = model.num_coarse, model.num_fine
-        bf16 = getattr(model, "bf16_mlp", False)
-        flags = ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
-                 | (_abi.BF16_MLP if bf16 else 0)
-                 | (_abi.SPLIT_MLP if getattr(model, "split_mlp", False) and not need_grad and not bf16 else 0))  # inference only
-        ws = model._workspace(B, flags)
+        flags = _call_flags(model, need_grad)
+        ws = model._workspace(B, flags)  # (inside NeRFModel.render: the frame's one workspace, sized for its longest call)
         # rendering loops (`with model.frozen_weights():`): the packed weight image a previous call of the SAME frozen section
         # left in this workspace is reused.  Outside such a section the image is rebuilt on every call (12 us): a version
         # stamp cannot see writes through `.data`, dist.broadcast or raw pointers.
@@ -169,6 +173,7 @@ class NeRFModel(nn.Module):
         #: into the bucket's flat buffer and makes p.grad its views (overwrite semantics: one backward per step, a second one before
         #: the gradients were consumed raises; autograd.grad / hooks unsupported), so the all-reduce needs no pack / unpack
         self.grad_bucket = None
+        self._ws_capacity = False  # True inside render(): an inference slot sized for more rays serves shorter calls too
         self._ws = {}            # flags -> (key, workspace): one slot per flag set (training / inference / bf16 ...)
         self._ws_generation = {}  # flags -> count of training forwards on that slot
         self._last_ws = None
@@ -182,6 +187,9 @@ class NeRFModel(nn.Module):
         dev = self.network.point_info.weight.device
         key = (B, self.num_coarse, self.num_fine, flags, dev)
         slot = self._ws.get(flags)
+        if slot is not None and self._ws_capacity and slot[0][1:] == key[1:] and slot[0][0] >= B and not (flags & _abi.SAVE_FOR_BACKWARD):
+            return slot[1]  # NeRFModel.render: calls of different lengths share the slot sized for the longest one (the regions in
+            #                 front of the per-ray ones -- status, packed weight images -- do not move with B: csrc/api.hip layout())
         if slot is None or slot[0] != key:
             self._ws.pop(flags, None)
             slot = None
@@ -220,6 +228,7 @@ class NeRFModel(nn.Module):
         d["_last_ws"] = None
         d["_packed"] = set()
         d["_frozen"] = False
+        d["_ws_capacity"] = False
         d["grad_bucket"] = None
         return d
 
@@ -229,6 +238,7 @@ class NeRFModel(nn.Module):
         self.__dict__.setdefault("split_mlp", False)
         self.__dict__["_ws"], self.__dict__["_ws_generation"] = {}, {}
         self.__dict__["_last_ws"], self.__dict__["_packed"], self.__dict__["_frozen"] = None, set(), False
+        self.__dict__["_ws_capacity"] = False
 
     def _params(self):
         ps = list(self.network.parameters())
@@ -251,6 +261,10 @@ class NeRFModel(nn.Module):
             raise RuntimeError("NeRFModel runs only on a ROCm device (MI355X): model.to('cuda'); there is no CPU path")
         if row.shape[0] != self.batch_ray:
             raise ValueError(f"batch of {row.shape[0]} rays, model built for batch_ray={self.batch_ray} (nerf.py:172-176)")
+        return self._launch(ps, row, column, poses_bound, K_inv)
+
+    def _launch(self, ps, row, column, poses_bound, K_inv):
+        dev = ps[0].device
         K9 = _abi.f32_array(K_inv.detach().to("cpu", torch.float32).reshape(-1).tolist())
         pb = poses_bound.to(torch.float).to(dev).contiguous()  # cast first like nerf.py:338
         row_d = row.to(dev, torch.int64).contiguous()
@@ -266,6 +280,64 @@ class NeRFModel(nn.Module):
             if st.value & _abi.STATUS_RESAMPLE_INDEX:
                 raise ResampleIndexError("resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253)")
         return C_c, C_f
+
+    @torch.no_grad()
+    def render(self, row, column, poses_bound, K_inv, lo: int = 0, hi: int | None = None, fuse_rays: int = 16384):
+        """Inference over a LONG list of rays (a frame, a test set) -- rays [lo, hi) of it -- with the reference's batch semantics and few
+        kernel calls: the list is the sequence of batches [g*batch_ray, (g+1)*batch_ray) the reference's display loop feeds to `forward`
+        (nerf.py:503-520), every ray gets exactly the bits a per-batch `forward` gives it (`fuse_plan`: consecutive batches whose ray 0
+        has the same near / far share a launch of up to `fuse_rays` rays), and a 400-ray batch size no longer means 400-ray launches
+        (0.71 of the fp32 roof, a fifth of the chip for the bf16 kernels).  The tail batch is rendered too (the reference drops it,
+        nerf.py:442), with its own ray 0.  The weights must not change during the call.  Returns (C_coarse, C_fine) [hi - lo, 3]."""
+        ps = self._params()
+        dev = ps[0].device
+        n, Bm = row.shape[0], self.batch_ray
+        hi = n if hi is None else hi
+        C_c = torch.empty(max(hi - lo, 0), 3, dtype=torch.float32, device=dev)
+        C_f = torch.empty_like(C_c)
+        if hi <= lo:
+            return C_c, C_f
+        starts = torch.arange(0, n, Bm)
+        nf0 = poses_bound[starts.to(poses_bound.device)][:, 15:17].to(torch.float32).cpu().tolist()  # ONE host copy per call
+        plan = fuse_plan(nf0, n, Bm, lo, hi, fuse_rays)
+        prev_ray0, prev_cap = self.ray0_near_far, self._ws_capacity
+        try:
+            self._ws_capacity = True
+            self._workspace(max(e - s for s, e, _, _ in plan), _call_flags(self, False))  # ONE workspace, sized for the longest call
+            with self.frozen_weights():
+                for s, e, near, far in plan:
+                    self.ray0_near_far = (near, far)
+                    c, f = self._launch(ps, row[s:e], column[s:e], poses_bound[s:e], K_inv)
+                    C_c[s - lo:e - lo] = c
+                    C_f[s - lo:e - lo] = f
+        finally:
+            self.ray0_near_far, self._ws_capacity = prev_ray0, prev_cap
+        return C_c, C_f
+
+
+def fuse_plan(near_far0, n: int, batch: int, lo: int = 0, hi: int | None = None, fuse_rays: int = 16384):
+    """Kernel calls that render rays [lo, hi) of an n-ray list with the reference's batch semantics.  The reference renders the list in
+    batches [g*batch, (g+1)*batch) and its resampler takes the coarse spacing from ray 0 OF EACH BATCH (nerf.py:233, quirk Q6) -- the
+    only cross-ray term of the path.  Consecutive batches whose ray 0 has the same (near, far) can therefore share one call that is
+    handed that pair: same bits per ray, fewer and fuller launches.  near_far0: [ceil(n / batch)][2] (near, far) of every batch's ray 0
+    (host floats).  Returns [(s, e, near, far)], s < e, each call inside one run of equal pairs and at most `fuse_rays` rays long
+    (at least one batch), pieces on the batch grid wherever the range allows it."""
+    hi = n if hi is None else hi
+    per_call = max(batch, fuse_rays // batch * batch)
+    plan = []
+    s = lo
+    while s < hi:
+        g = s // batch
+        nf = (float(near_far0[g][0]), float(near_far0[g][1]))
+        e = min((g + 1) * batch, hi)
+        while e < hi and e - s + batch <= per_call:  # take the next batch along if its ray 0 agrees
+            g2 = e // batch
+            if (float(near_far0[g2][0]), float(near_far0[g2][1])) != nf:
+                break
+            e = min((g2 + 1) * batch, hi)
+        plan.append((s, e, nf[0], nf[1]))
+        s = e
+    return plan
 
 
 class _RayLossFn(torch.autograd.Function):

@@ -146,41 +146,19 @@ def batch_shard_bounds(n: int, batch: int, rank: int, world: int) -> tuple[int, 
 
 
 def render_rows_sharded(model, row, col, poses_bound, K_inv, rank: int, world: int, out: torch.Tensor | None = None,
-                        align_to_batches: bool = True):
+                        align_to_batches: bool = True, fuse_rays: int = 16384):
     """Inference over a long list of rays (e.g. one frame): this rank renders a contiguous range [lo, hi) in batches of
     model.batch_ray.  No collective.  Returns (lo, hi, C_fine[hi-lo, 3]).
 
     The reference renders the list in DataLoader batches [g*Bm, (g+1)*Bm) and its resampler takes the coarse spacing from
     ray 0 OF EACH BATCH (nerf.py:233, quirk Q6).  To return the same pixels for any sharding, every kernel call here covers
-    rays of ONE reference batch and is handed that batch's ray 0 (near, far); with `align_to_batches` (default) shards start
-    on the batch grid, so only the global tail batch is short.  A short piece is padded by repeating its last ray and cropped
-    (the reference silently drops the tail batch, nerf.py:442; here it is rendered, with its own ray 0)."""
+    rays of reference batches that agree in their ray 0's (near, far) and is handed that pair (`nerf.fuse_plan`; `fuse_rays` = the
+    longest call, `model.batch_ray` = one call per batch as up to round 2); with `align_to_batches` (default) shards start
+    on the batch grid.  The reference silently drops the tail batch (nerf.py:442); here it is rendered, with its own ray 0."""
     n, Bm = row.shape[0], model.batch_ray
     lo, hi = batch_shard_bounds(n, Bm, rank, world) if align_to_batches else shard_bounds(n, rank, world)
-    res = []
-    prev_ray0 = model.ray0_near_far
-    try:
-        if hi > lo:
-            g0, g1 = lo // Bm, (hi - 1) // Bm
-            starts = torch.arange(g0, g1 + 1) * Bm
-            nf0 = poses_bound[starts.to(poses_bound.device)][:, 15:17].to(torch.float32).cpu()  # ONE host copy for the whole range
-        with torch.no_grad(), model.frozen_weights():
-            s = lo
-            while s < hi:
-                g = s // Bm
-                e = min((g + 1) * Bm, hi)
-                model.ray0_near_far = (float(nf0[g - g0, 0]), float(nf0[g - g0, 1]))
-                if e - s == Bm:
-                    r, c, pb = row[s:e], col[s:e], poses_bound[s:e]
-                else:
-                    idx = torch.arange(s, s + Bm, device=row.device).clamp_max(e - 1)
-                    r, c, pb = row[idx], col[idx], poses_bound[idx.to(poses_bound.device)]
-                _, C_f = model(r, c, pb, K_inv)
-                res.append(C_f[: e - s].clone())
-                s = e
-    finally:
-        model.ray0_near_far = prev_ray0
-    C = torch.cat(res) if res else torch.empty(0, 3)
+    # NeRFModel.render: the batches of this range that share their ray 0's (near, far) share kernel calls (same bits per ray)
+    C = model.render(row, col, poses_bound, K_inv, lo, hi, fuse_rays=fuse_rays)[1] if hi > lo else torch.empty(0, 3)
     if out is not None and hi > lo:
         out[lo:hi] = C
     return lo, hi, C

@@ -411,3 +411,39 @@ def test_near_equal_far_is_flagged_where_the_reference_exits(oracle, pkg, dev):
         assert torch.isfinite(Cc).all() and torch.isfinite(Cf).all() and float(Cc[5].abs().max()) == 0.0
         d_cam, d_wrd, t_c = pkg.ops.rays(row.to(dev), col.to(dev), pb2.float().to(dev), K, 64)
         assert torch.equal(t_c[5].cpu(), torch.full((64,), float(pb2[5, 15].float())))  # numpy.linspace gives start everywhere, too
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "split"])
+def test_render_fuses_batches_bit_identically(oracle, pkg, dev, mode):
+    """NeRFModel.render: the reference's batches [g*Bm, (g+1)*Bm) whose ray 0 has the same (near, far) share kernel calls (quirk Q6 is
+    the only cross-ray term) -- every ray must get exactly the bits the per-batch `forward` gives it, whatever the kernel variant;
+    where the pair changes inside the list the calls split; the tail batch is rendered with its own ray 0."""
+    n, Bm = 2500, 400
+    row, col, pb, K, _ = oracle.lego_inputs(n, seed=21)
+    pb = pb.clone()
+    pb[1300:, 15] = 2.5   # a second "picture" with its own near / far from ray 1300 on: batch 3 (rays 1200..1599) still starts in the first
+    pb[1300:, 16] = 5.5
+    w = oracle.make_weights(5, sharp=True)
+    m = pkg.NeRFModel(64, 128, Bm)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    m.bf16_mlp, m.split_mlp = mode == "bf16", mode == "split"
+    rd, cd, pd = row.to(dev), col.to(dev), pb.to(dev)
+    nf0 = pb[::Bm, 15:17].float().tolist()
+    plan = pkg.nerf.fuse_plan(nf0, n, Bm)
+    assert [(s, e) for s, e, _, _ in plan] == [(0, 1600), (1600, 2500)]  # batches 0-3 (ray 0 in picture one), batches 4-6 (tail included)
+    Cc, Cf = m.render(rd, cd, pd, K)
+    Cc1, Cf1 = m.render(rd, cd, pd, K, fuse_rays=Bm)  # one call per batch
+    assert torch.equal(Cf, Cf1) and torch.equal(Cc, Cc1)
+    with torch.no_grad():
+        for s in range(0, n - Bm + 1, Bm):  # the reference's own loop over the full batches
+            c, f = m(rd[s:s + Bm], cd[s:s + Bm], pd[s:s + Bm], K)
+            assert torch.equal(Cf[s:s + Bm], f) and torch.equal(Cc[s:s + Bm], c), s
+    # a sub-range that starts and ends off the batch grid: the same pixels
+    _, Cf2 = m.render(rd, cd, pd, K, 333, 2222)
+    assert torch.equal(Cf2, Cf[333:2222])
+    if mode == "f32":  # and they are the reference's (oracle) pixels, batch by batch with that batch's ray 0
+        for s in (1200, 2400):
+            e = min(s + Bm, n)
+            _, of = oracle.render(w, row[s:e], col[s:e], pb[s:e], K, 64, 128)
+            assert max_rel(Cf[s:e], of) < TOL, s
