@@ -2,7 +2,7 @@
 gradients re-computed in torch from the workspace's own G / save / dz buffers (dW = G^T X, fp32 matmuls) and compared with what
 libnerf_hip wrote.  A rare wrong launch of the weight-gradient kernels (a race, a stale operand) shows up as one step with a
 large relative error; rounding differences stay below 1e-3.
-Usage:  python tests/tools/train_dw_check.py [iterations] [seed]
+Usage:  [BATCH=400] python tests/tools/train_dw_check.py [iterations] [seed]      (BATCH: rays per step, default 4096)
 """
 import os
 import sys
@@ -27,7 +27,7 @@ def main():
     torch.backends.cuda.matmul.allow_tf32 = False
     dev = torch.device("cuda:0")
     H = W = 64
-    B, Nc, Nf = 4096, 64, 128
+    B, Nc, Nf = int(os.environ.get("BATCH", "4096")), 64, 128
     scene = P.data.analytic_sphere_scene(n_pic=24, H=H, W=W, seed=5, device=dev)
     poses, imgs = scene.poses_bounds, scene.all_pix.view(24, H, W, 3)
     test_idx = np.arange(0, 24, 6)
