@@ -44,6 +44,14 @@ __device__ __forceinline__ unsigned alive_bits(const f32x16& A) {
   return ~bits & 0xffffu;
 }
 
+// The lane id, produced AT this program point (volatile: never merged with an earlier copy, which would have to stay alive -- or be
+// parked in scratch -- across the stream): what the epilogues of the stream kernels form their addresses from.
+__device__ __forceinline__ unsigned lane_id_here() {
+  unsigned l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt range");

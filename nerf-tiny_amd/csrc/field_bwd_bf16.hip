@@ -98,12 +98,13 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
            c.lds_base + (c.wv * BM_LAYERS + l) * 1024);
   bf_stream_start<S>(c);
 
-  unsigned char* const gvl = a.bG + lane * 16;
-  auto grad_piece = [&](int tensor, int ks, const u32x4& v) {
-    store_piece(gvl + ((size_t)a.wb_tot * bg_cum(tensor) + (size_t)wb * bg_ks(tensor) + ks) * BF_FRAG_BYTES, v);
+  // `lane16` = this lane's byte offset inside a piece; the epilogues pass one produced at THEIR program point (lane_id_here): an
+  // address register kept from the prologue lives across the whole stream -- the allocator parked five of them in scratch
+  auto grad_piece = [&](int tensor, int ks, const u32x4& v, unsigned lane16) {
+    store_piece(a.bG + ((size_t)a.wb_tot * bg_cum(tensor) + (size_t)wb * bg_ks(tensor) + ks) * BF_FRAG_BYTES + lane16, v);
   };
-  grad_piece(BG_Z, 0, zin[0]);
-  grad_piece(BG_Z, 1, zin[1]);
+  grad_piece(BG_Z, 0, zin[0], lane * 16);
+  grad_piece(BG_Z, 1, zin[1], lane * 16);
 
   u32x4 fr[S::D];
   bf_stream_first<S>(c, fr);
@@ -128,9 +129,10 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[2 * f + mh][q] = pack2(D[8 * mh + 2 * q], D[8 * mh + 2 * q + 1]);
       if (f == ntiles - 1) {  // the whole gradient tensor of this wave block in one contiguous burst
+        const unsigned lane16 = 16u * lane_id_here();
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
-          if (ks < 2 * ntiles) grad_piece(tensor, ks, out[ks]);
+          if (ks < 2 * ntiles) grad_piece(tensor, ks, out[ks], lane16);
       }
     };
   };
@@ -158,16 +160,24 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
     // One segment: tile f of d gamma_p runs over the 16 k-steps of dpre0 (X, W_0^T) and then the 16 k-steps of dpre4 (Y, W_4[:, 256:]^T)
     // in the same accumulator (the weight image interleaves the two matrices per tile): no second accumulator pair to add up.
     f32x16 dgp[2];
+    {
+      const unsigned lane16 = 16u * lane_id_here();
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      Y[ks] = *reinterpret_cast<const u32x4*>(gvl + ((size_t)a.wb_tot * bg_cum(BG_L0 + 4) + (size_t)wb * 16 + ks) * BF_FRAG_BYTES);
+      for (int ks = 0; ks < 16; ++ks)
+        Y[ks] = *reinterpret_cast<const u32x4*>(a.bG + ((size_t)a.wb_tot * bg_cum(BG_L0 + 4) + (size_t)wb * 16 + ks) * BF_FRAG_BYTES + lane16);
+    }
     bf_segment<S, BBS_G0T, 2, 16, 16, -1, 0, -1>(c, fr, acc, X, Y, [&](int, const f32x16& A) { dgp[0] = A; },
                                                  last_of(grad_to(X, BG_L0 + 0, 0), 7));
     dgp[1] = acc[1];
     // gamma -> point -> depth (t_fine is not detached, quirk Q9).  dgp[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of
     // pair pi = 16t + 4g + 2h + e
-    int mcl = mc;
-    asm volatile("" : "+v"(mcl));  // keeps the geometry loads and the 16 sincos below from being hoisted over the stream
+    // (the sample index is re-derived from the lane id HERE: nothing of the prologue stays alive across the stream, and the geometry
+    // loads and the 16 sincos below cannot be hoisted over it)
+    const int lane_e = (int)lane_id_here();
+    const int h_e = lane_e >> 5;
+    const int m_e = blockIdx.x * (BF_WG / 2) + c.wv * 32 + (lane_e & 31);
+    const bool valid_e = m_e < a.M;
+    const int mcl = valid_e ? m_e : a.M - 1;
     const int ray = mcl / a.N;
     const float* rf = a.rayf + (size_t)ray * RAYF;
     float p[3];
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
     for (int g8 = 0; g8 < 8; ++g8)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int pi = 4 * g8 + 2 * h + e;
+        const int pi = 4 * g8 + 2 * h_e + e;
         if (pi < 30) {
           const int cc = pi / 10, l = pi - 10 * cc;
           const float x = (cc == 0) ? p[0] : ((cc == 1) ? p[1] : p[2]);
@@ -191,9 +201,9 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
       }
 #pragma unroll
     for (int i = 0; i < 3; ++i) dp[i] += __shfl_xor(dp[i], 32);
-    if (valid && h == 0) {
+    if (valid_e && h_e == 0) {
       const float dtp = __builtin_fmaf(rf[RF_DWRD + 2], dp[2], __builtin_fmaf(rf[RF_DWRD + 1], dp[1], rf[RF_DWRD] * dp[0]));
-      a.dt[m] += dtp;
+      a.dt[m_e] += dtp;
     }
   }
 }

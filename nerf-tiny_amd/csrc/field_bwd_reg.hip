@@ -309,9 +309,16 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
     // d gamma / d x needs (cos, -sin) of the same phases: they ARE the saved layer-0 input (tensor S_GP: this lane's eight
     // 16-byte groups hold exactly its pairs), so they are loaded, not recomputed -- 8 loads instead of ~15 sincos with their
     // float64 argument reductions behind the last MFMA, where nothing overlaps them.
-    const int ray = mc / a.N;
-    const float* rf = a.rayf + (size_t)ray * RAYF;
-    const float* gprow = srow + S_GP * MS;
+    // (this lane's row and ray are re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing of the prologue
+    // stays alive across 8,200 MFMAs, where the allocator used to park four address registers in scratch)
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int j_e = lane_e & 31, h_e = lane_e >> 5;
+    const int m_e = blockIdx.x * RMB + j_e;
+    const bool valid_e = m_e < a.M;
+    const int mc_e = valid_e ? m_e : a.M - 1;
+    const long long rrow_e = valid_e ? (long long)(a.row0 + m_e) : a.Mtot + j_e;
+    const float* rf = a.rayf + (size_t)(mc_e / a.N) * RAYF;
+    const float* gprow = a.save + (size_t)rrow_e * WIDTH + 4 * h_e + S_GP * ((size_t)a.MSrows * WIDTH);
     float4 gq[8];
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) gq[g8] = *reinterpret_cast<const float4*>(gprow + 8 * g8);
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
     for (int g8 = 0; g8 < 8; ++g8)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int pi = 4 * g8 + 2 * h + e;
+        const int pi = 4 * g8 + 2 * h_e + e;
         if (pi < 30) {
           const int c = pi / 10, l = pi - 10 * c;
           const float fl = __uint_as_float(kFreqPointBits[l]);
@@ -332,9 +339,9 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
       }
 #pragma unroll
     for (int c = 0; c < 3; ++c) dp[c] += __shfl_xor(dp[c], 32);
-    if (valid && h == 0) {
+    if (valid_e && h_e == 0) {
       const float dtp = __builtin_fmaf(rf[RF_DWRD + 2], dp[2], __builtin_fmaf(rf[RF_DWRD + 1], dp[1], rf[RF_DWRD] * dp[0]));
-      a.dt[m] += dtp;
+      a.dt[m_e] += dtp;
     }
   } else {
 #pragma unroll

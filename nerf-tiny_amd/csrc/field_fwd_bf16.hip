@@ -44,6 +44,9 @@ constexpr BfStoreTable<BF_NFRAG> make_fwd_store_table() {
 }
 constexpr BfStoreTable<BF_NFRAG> kFwdStoreTable = make_fwd_store_table();
 
+constexpr int BFW_LDS_BYTES = BF_LDS_BYTES + BF_WG * 32;  // bias block + ring + 32 bytes per lane of parked direction encodings = 160 KiB
+static_assert(BFW_LDS_BYTES <= 160 * 1024, "LDS of one CU");
+
 template <bool SAVE>
 struct FwdStream {
   static constexpr int NFRAG = BF_NFRAG, NCHUNK = BF_NCHUNK, NS = BF_NS, RING_OFF = BF_BIAS_BYTES, D = BF_D;
@@ -126,18 +129,24 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
 #else
   const int wb = a.wb0 + blockIdx.x * (BF_WG / 64) + c.wv;
 #endif
-  unsigned char* const svl = SAVE ? a.bsave + lane * 16 : nullptr;
-  unsigned char* const mkl = SAVE ? reinterpret_cast<unsigned char*>(a.bmask) + lane * 16 : nullptr;
-  unsigned mw[4] = {0u, 0u, 0u, 0u};
-  auto save_piece = [&](int tensor, int ks, const u32x4& v) {
-    store_piece(svl + ((size_t)a.wb_tot * bs_cum(tensor) + (size_t)wb * bs_ks(tensor) + ks) * BF_FRAG_BYTES, v);
+  unsigned mw[4];  // (every word is assigned by its even tile before the odd one ORs into it; words 2, 3 of a 4-tile layer are written as 0)
+  // `lane16` = this lane's byte offset inside a piece.  The layers' epilogues pass a value produced AT their program point (mbcnt): left
+  // alone the compiler forms every layer's 64-bit store address in the prologue and parks them -- and the lane pointer -- in scratch
+  auto save_piece = [&](int tensor, int ks, const u32x4& v, unsigned lane16) {
+    store_piece(a.bsave + ((size_t)a.wb_tot * bs_cum(tensor) + (size_t)wb * bs_ks(tensor) + ks) * BF_FRAG_BYTES + lane16, v);
   };
   if (SAVE) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) save_piece(BS_GP, ks, gp[ks]);
+    for (int ks = 0; ks < 4; ++ks) save_piece(BS_GP, ks, gp[ks], lane * 16);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) save_piece(BS_GD, ks, gd[ks]);
+    for (int ks = 0; ks < 2; ++ks) save_piece(BS_GD, ks, gd[ks], lane * 16);
   }
+
+  // the direction encodings are needed 976 fragments later: parked in the 16 KiB of LDS behind the ring (32 bytes per lane) instead of
+  // 8 registers the allocator would spill to scratch (as in field_fwd_bf16x.hip)
+  u32x4* const gd_park = reinterpret_cast<u32x4*>(lds + BF_LDS_BYTES) + 2 * threadIdx.x;
+  gd_park[0] = gd[0];
+  gd_park[1] = gd[1];
 
   // ---- bias block and chunk 0 have landed (mine), then everybody's
   u32x4 fr[S::D];
@@ -167,11 +176,12 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
         else
           mw[f >> 1] = alive_bits(A);
         if (f == ntiles - 1) {  // the layer's output is complete: one contiguous burst
+          const unsigned lane16 = 16u * lane_id_here();
           u32x4 mv = {mw[0], mw[1], ntiles > 4 ? mw[2] : 0u, ntiles > 4 ? mw[3] : 0u};
-          store_piece(mkl + ((size_t)mlayer * a.wb_tot + wb) * 1024, mv);
+          store_piece(reinterpret_cast<unsigned char*>(a.bmask) + ((size_t)mlayer * a.wb_tot + wb) * 1024 + lane16, mv);
 #pragma unroll
           for (int ks = 0; ks < 16; ++ks)
-            if (ks < 2 * ntiles) save_piece(tensor, ks, out[ks]);
+            if (ks < 2 * ntiles) save_piece(tensor, ks, out[ks], lane16);
         }
       }
     };
@@ -195,17 +205,27 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   bf_segment<S, BFS_SIG, 1, 16, 0, BFB_SIGMA, 0, BFB_DIR>(c, fr, acc, Y, nullptr, nothing_f, last_of(relu_to(Y, BS_H0 + 7, 7), 7));
   // ---- point_info folded into dir_info (bf16_common.h): c = relu(W_dir[:, :24] gamma_d + W_fold h7 + b_dir + W_dir[:, 24:] b_pi)
   // (nerf.py:117-118); its first tile also retires the sigma tile
+  {
+    const int lane_d = (int)lane_id_here();  // (re-derived: no address register kept across the stream)
+    const u32x4* const back = reinterpret_cast<const u32x4*>(lds + BF_LDS_BYTES) + 2 * (c.wv * 64 + lane_d);
+    gd[0] = back[0];
+    gd[1] = back[1];
+  }
   bf_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd, Y, relu_to(X, BS_C, 8, 4), sig_epi);
-  if (valid && h == 0) {
-    a.sigma[m] = fabsf(spre);
-    if (SAVE) a.spre[a.row0 + m] = spre;
+  // (the sample index is re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing to keep alive or spill)
+  const int lane_e = (int)lane_id_here();
+  const int m_e = blockIdx.x * (BF_WG / 2) + c.wv * 32 + (lane_e & 31);
+  const bool out_e = m_e < a.M && lane_e < 32;
+  if (out_e) {
+    a.sigma[m_e] = fabsf(spre);
+    if (SAVE) a.spre[a.row0 + m_e] = spre;
   }
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
   bf_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X, BS_C, 8, 4), 3));
-  if (valid && h == 0) {
-    a.rgb[(size_t)m * 3 + 0] = 1.0f / (1.0f + expf(-acc[1][0]));
-    a.rgb[(size_t)m * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
-    a.rgb[(size_t)m * 3 + 2] = 1.0f / (1.0f + expf(-acc[1][2]));
+  if (out_e) {
+    a.rgb[(size_t)m_e * 3 + 0] = 1.0f / (1.0f + expf(-acc[1][0]));
+    a.rgb[(size_t)m_e * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
+    a.rgb[(size_t)m_e * 3 + 2] = 1.0f / (1.0f + expf(-acc[1][2]));
   }
 }
 
@@ -246,12 +266,12 @@ hipError_t launch_pack_bias_block_bf16(const Weights24& w, const float* fold, un
 
 hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st) {
   static std::atomic<unsigned long long> opted{0};  // >64 KiB of dynamic LDS needs an opt-in, once per device and kernel
-  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16<false>), reinterpret_cast<const void*>(&k_field_fwd_bf16<true>)}, BF_LDS_BYTES)) return e;
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16<false>), reinterpret_cast<const void*>(&k_field_fwd_bf16<true>)}, BFW_LDS_BYTES)) return e;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
   if (save)
-    hipLaunchKernelGGL((k_field_fwd_bf16<true>), dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_fwd_bf16<true>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a);
   else
-    hipLaunchKernelGGL((k_field_fwd_bf16<false>), dim3(wgs), dim3(BF_WG), BF_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_fwd_bf16<false>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 
