@@ -74,9 +74,13 @@ __device__ __forceinline__ void sp_segment(const BfCtx& c, u32x4 (&fr)[S::D], f3
     };
     if constexpr (i0 % BF_CHUNK == BF_SYNC_POS) bf_sync<S, i0 / BF_CHUNK>(c);
     const u32x4 a_hi = fr[i0 % S::D];
+#ifndef NERF_TIMING_NO_FRAG  // (timing experiments only)
     if constexpr (i0 + S::D < S::NFRAG) fr[i0 % S::D] = bf_frag<S>(c, i0 + S::D);
+#endif
     const u32x4 a_mid = fr[i1 % S::D];
+#ifndef NERF_TIMING_NO_FRAG
     if constexpr (i1 + S::D < S::NFRAG) fr[i1 % S::D] = bf_frag<S>(c, i1 + S::D);
+#endif
     const u32x4& b_hi = ks < KSA ? inA_hi[ks < KSA ? ks : 0] : inB_hi[ks < KSA ? 0 : ks - KSA];
     const u32x4& b_mid = ks < KSA ? inA_mid[ks < KSA ? ks : 0] : inB_mid[ks < KSA ? 0 : ks - KSA];
     // program order = issue order for one wave per SIMD: every MFMA is followed by its share of vector work, and the fences keep
@@ -149,7 +153,11 @@ __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a)
       if (pi < 30) {
         const int cc = pi / 10, l = pi - 10 * cc;
         const float x = (cc == 0) ? p[0] : ((cc == 1) ? p[1] : p[2]);
+#ifdef NERF_TIMING_NO_SINCOS  // (timing experiments only)
+        sv = x; cv = x * 0.5f;
+#else
         sincos_phase(x * __uint_as_float(kFreqPointBits[l]), sv, cv);
+#endif
       }
       const HiMid e = split2(sv, cv);
       gp_hi[ks][q] = e.hi;
@@ -164,7 +172,11 @@ __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a)
       if (pi < 12) {
         const int cc = pi / 4, l = pi - 4 * cc;
         const float x = (cc == 0) ? dw[0] : ((cc == 1) ? dw[1] : dw[2]);
+#ifdef NERF_TIMING_NO_SINCOS
+        sv = x; cv = x * 0.5f;
+#else
         sincos_phase(x * __uint_as_float(kFreqDirBits[l]), sv, cv);
+#endif
       }
       const HiMid e = split2(sv, cv);
       gd_hi[ks][q] = e.hi;
