@@ -272,14 +272,20 @@ class NeRFModel(nn.Module):
         ray0 = _abi.f32_array(self.ray0_near_far) if self.ray0_near_far is not None else None
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in ps)  # grad mode is off inside Function.forward
         C_c, C_f = _RenderFn.apply(self, need_grad, row_d, col_d, pb, K9, ray0, *ps)
-        if self.check_resample:
-            st = C.c_uint32(0)
-            ws = self._last_ws
-            _abi.check(_abi.lib().nerf_hip_read_status(ws.data_ptr(), ws.numel(), C.byref(st),
-                                                       torch.cuda.current_stream(dev).cuda_stream))
-            if st.value & _abi.STATUS_RESAMPLE_INDEX:
-                raise ResampleIndexError("resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253)")
+        if self.check_resample and self.resample_fault():
+            raise ResampleIndexError("resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253)")
         return C_c, C_f
+
+    def resample_fault(self) -> bool:
+        """Did the most recent forward meet the reference's exit condition -- a ray whose resampling index falls outside [0, Nf-1], i.e.
+        whose coarse weights all vanished (nerf.py:251-253: banner + exit(0))?  The device path clamps the index and goes on; this reads
+        the status word the kernels left (ONE host sync)."""
+        ws = self._last_ws
+        if ws is None:
+            return False
+        st = C.c_uint32(0)
+        _abi.check(_abi.lib().nerf_hip_read_status(ws.data_ptr(), ws.numel(), C.byref(st), torch.cuda.current_stream(ws.device).cuda_stream))
+        return bool(st.value & _abi.STATUS_RESAMPLE_INDEX)
 
     @torch.no_grad()
     def render(self, row, column, poses_bound, K_inv, lo: int = 0, hi: int | None = None, fuse_rays: int = 16384):

@@ -91,12 +91,14 @@ class NeRFRunner:
     and ``display()`` (nerf.py:503).  ``mode`` defaults to "train" so the reference's ``main.py:55`` call works.
     Extra keyword-only arguments: ``datasets`` (dict mode -> dataset, to run without files), ``log_every`` (host sync
     period; the reference syncs every iteration), ``bf16_mlp`` (BASELINE.json cfg3: the MLP on bf16 MFMA, default off), ``split_mlp`` (rendering calls -- validation,
-    ``display()`` -- on the split-fp32 inference kernels: same 1e-4 bar, 3x the rate; training forwards ignore it; default off)."""
+    ``display()`` -- on the split-fp32 inference kernels: same 1e-4 bar, 3x the rate; training forwards ignore it; default off),
+    ``on_resample_fault`` ("warn" | "raise" | "ignore": what to do when a logged iteration meets the reference's exit(0) condition of
+    nerf.py:251-253 -- a training run that has died; the device path itself clamps the index and goes on)."""
 
     def __init__(self, gpu=0, img_dir="../nerf_synthetic/lego/", results_path="./results/", ckpt_path="./checkpoint/", low_res=1,
                  total_iter=100000, batch_ray=400, learning=1e-3, lr_gamma=0.1, lr_milestone=(10, 200), n_coarse=64, n_fine=128,
                  data_type="sync", step=100, decay_end=200000, sched="EXP", continue_=False, *, datasets=None, log_every=None,
-                 seed=624, bf16_mlp=False, split_mlp=False):
+                 seed=624, bf16_mlp=False, split_mlp=False, on_resample_fault="warn"):
         from . import nerf as _nerf
 
         if not torch.cuda.is_available():
@@ -109,6 +111,10 @@ class NeRFRunner:
         self.results_path, self.ckpt_path, self.low_res = results_path, ckpt_path, low_res
         self.total_iter, self.batch_ray, self.step, self.decay_end = total_iter, batch_ray, step, decay_end
         self.log_every = log_every or step
+        if on_resample_fault not in ("warn", "raise", "ignore"):
+            raise ValueError("on_resample_fault: 'warn', 'raise' or 'ignore'")
+        self.on_resample_fault = on_resample_fault
+        self.resample_fault_iter = None  # first logged iteration at which the reference's exit(0) condition was seen
         self.model = NeRFModel(num_coarse=n_coarse, num_fine=n_fine, batch_ray=batch_ray).to(self.device)
 
         # resume: newest "<anything>_<iter>.pkl" (nerf.py:404-415)
@@ -169,6 +175,17 @@ class NeRFRunner:
                     self.writer.flush()
                     print(f"[ITER] {it} [LOSS] {lv:.4f} [LR] {self.optimizer.param_groups[0]['lr']:.3e} "
                           f"[{(it + 1 - n0) * self.batch_ray / max(dt, 1e-9):,.0f} rays/s]")
+                    # the reference checks its resampling indices in every forward and exit(0)s when a ray's coarse weights have all
+                    # vanished (nerf.py:251-253) -- the state a run that has died stays in.  Looked at here, where the loop syncs anyway
+                    if self.on_resample_fault != "ignore" and self.model.resample_fault():
+                        if self.resample_fault_iter is None:
+                            self.resample_fault_iter = it
+                            print(f"[ITER] {it} resample index out of range: the reference prints its banner and exit(0)s here "
+                                  "(nerf.py:251-253); this path clamps the index and trains on (NeRFRunner(on_resample_fault='raise') stops)")
+                        if self.on_resample_fault == "raise":
+                            from .nerf import ResampleIndexError
+
+                            raise ResampleIndexError(f"iteration {it}: resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253)")
                 if (it + 1) % self.step == 0:
                     os.makedirs(self.ckpt_path, exist_ok=True)
                     torch.save(self.model, self.ckpt_path + self.start_time + "_" + str(it) + ".pkl")

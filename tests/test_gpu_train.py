@@ -279,3 +279,33 @@ def test_training_trajectory_follows_the_oracle_with_torch_adam(oracle, pkg, dev
     assert dev_l[-1] < 0.6 * dev_l[0] and ref_l[-1] < 0.6 * ref_l[0]  # both trainers learn (93 -> 40)
     print(f"trajectory: {steps} steps, loss {ref_l[0]:.3f} -> {ref_l[-1]:.3f} (oracle) / {dev_l[-1]:.3f} (device); teacher-forced worst rel {worst_tf:.1e}; "
           f"free-running largest |dev - oracle| / bar = {worst:.2f}; the oracle's own 1e-6 drift at the last step: {band_l[-1] / ref_l[-1]:.1e} rel")
+
+
+def test_runner_reports_the_references_exit_condition(pkg, dev, tmp_path):
+    """nerf.py:251-253: the reference prints a banner and exit(0)s when a ray's resampling index leaves [0, Nf-1] -- all coarse weights of
+    the ray vanished, the state a training run that has died stays in (tests/tools/collapse_stats.py: the reference's own recipe reaches it
+    in a third of the runs at its default learning rate).  The device path clamps and trains on; the runner looks at the status word where
+    it syncs anyway and warns (default), raises, or ignores."""
+    scene = pkg.data.synthetic_scene(n_pic=2, H=16, W=16, seed=3)
+    kw = dict(gpu=0, img_dir="", results_path=str(tmp_path) + "/r/", ckpt_path=str(tmp_path) + "/c/", low_res=1, total_iter=4, batch_ray=128,
+              learning=1e-5, n_coarse=16, n_fine=32, step=10 ** 9, decay_end=10000, sched="EXP", datasets={"train": scene, "val": scene, "test": scene},
+              log_every=2)
+
+    def dead(run):  # sigma = |0 . h7 + 0| = 0 everywhere: every ray's coarse weights vanish
+        with torch.no_grad():
+            run.model.network.sigma_layer[0].weight.zero_()
+            run.model.network.sigma_layer[0].bias.zero_()
+
+    run = pkg.NeRFRunner(**kw)
+    run.trainer("train")
+    assert run.resample_fault_iter is None and not run.model.resample_fault()  # a healthy run says nothing
+    run = pkg.NeRFRunner(**kw)
+    dead(run)
+    assert run.trainer("train") == 3 and run.resample_fault_iter == 1  # warned at the first logged iteration, trained on
+    run = pkg.NeRFRunner(on_resample_fault="raise", **kw)
+    dead(run)
+    with pytest.raises(pkg.nerf.ResampleIndexError):
+        run.trainer("train")
+    run = pkg.NeRFRunner(on_resample_fault="ignore", **kw)
+    dead(run)
+    assert run.trainer("train") == 3 and run.resample_fault_iter is None
