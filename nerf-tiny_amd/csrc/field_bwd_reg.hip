@@ -30,12 +30,10 @@ __device__ __forceinline__ unsigned mask_word(const uint16_t* __restrict__ mlaye
 // is stored to the G rows (lanes past the end of the pass own a dump row, so the stores carry no predicate).
 // Two fragment stages as in k_field_fwd_reg; st0 = k-block 0 on entry / next segment's k-block 0 on exit.
 template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT, bool MASK_IN, bool STORE = true, bool HAS_NEXT_MASK = MASK_IN>
-__device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
+__device__ __forceinline__ void reg_layer_bwd(const int seg, const int next_seg /* float4 offsets into the packed image; < 0: none */, int lane,
                                               const f32x16* prev, f32x16* acc, WStageB<8>& st0, const uint16_t* __restrict__ mlayer,
-                                              const uint16_t* __restrict__ mnext, unsigned& mfirst, float* __restrict__ grow) {
+                                              const uint16_t* __restrict__ mnext, unsigned& mfirst, float* __restrict__ grow, const RegBuf& rb) {
   constexpr int KT = KB / 4;
-  const float4* sl = seg + lane;
-  const float4* nl = next_seg + lane;
   WStageB<8> st1;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 tin[2];
@@ -67,10 +65,10 @@ __device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, co
   auto kblock = [&](int kb, const WStageB<8>& cur, WStageB<8>& ld) {
     if (kb + 1 < KB) {
 #pragma unroll
-      for (int f = 0; f < NFT; ++f) ld.w[f] = sl[(size_t)(f * KB + kb + 1) * 64];
-    } else if (next_seg != nullptr) {
+      for (int f = 0; f < NFT; ++f) ld.w[f] = reg_ldw(rb, seg + (int)(f * KB + kb + 1) * 64);
+    } else if (next_seg >= 0) {
 #pragma unroll
-      for (int f = 0; f < NNFT; ++f) ld.w[f] = nl[(size_t)(f * NKB) * 64];
+      for (int f = 0; f < NNFT; ++f) ld.w[f] = reg_ldw(rb, next_seg + (int)(f * NKB) * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
     if ((kb & 3) == 2 && (kb >> 2) + 1 < KT) activate((kb >> 2) + 1);
@@ -99,13 +97,11 @@ __device__ __forceinline__ void reg_layer_bwd(const float4* __restrict__ seg, co
 // form a ring of 8 k-blocks: requests run 8 k-blocks (4096 cycles) ahead.  st0.w[0..1] = k-block 0 on entry; on exit st0
 // holds the next segment's k-block 0 (NNFT tiles), requested at k-block KB - 4 when st0's half of the ring has drained.
 template <int KB, int NKB, int NNFT, bool ZERO_INIT, bool STORE, bool HAS_NEXT_MASK>
-__device__ __forceinline__ void reg_layer_bwd_thin(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
+__device__ __forceinline__ void reg_layer_bwd_thin(const int seg, const int next_seg /* float4 offsets into the packed image; < 0: none */, int lane,
                                                    const f32x16* prev, f32x16* acc, WStageB<8>& st0, const uint16_t* __restrict__ mlayer,
-                                                   const uint16_t* __restrict__ mnext, unsigned& mfirst, float* __restrict__ grow) {
+                                                   const uint16_t* __restrict__ mnext, unsigned& mfirst, float* __restrict__ grow, const RegBuf& rb) {
   static_assert(KB == 32, "ring indexing below assumes 32 k-blocks");
   constexpr int KT = KB / 4, D = 8;
-  const float4* sl = seg + lane;
-  const float4* nl = next_seg + lane;
   WStageB<8> st1;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 tin[2];
@@ -131,7 +127,7 @@ __device__ __forceinline__ void reg_layer_bwd_thin(const float4* __restrict__ se
 #pragma unroll
   for (int kb = 1; kb < D; ++kb)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) slot(kb, f) = sl[(size_t)(f * KB + kb) * 64];
+    for (int f = 0; f < 2; ++f) slot(kb, f) = reg_ldw(rb, seg + (int)(f * KB + kb) * 64);
   activate(0);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
@@ -152,10 +148,10 @@ __device__ __forceinline__ void reg_layer_bwd_thin(const float4* __restrict__ se
     // the slot just consumed takes k-block kb + D; once the ring's st0 half has drained for good it takes the next segment
     if (kb + D < KB) {
 #pragma unroll
-      for (int f = 0; f < 2; ++f) slot(kb, f) = sl[(size_t)(f * KB + kb + D) * 64];
-    } else if (kb == KB - 4 && next_seg != nullptr) {
+      for (int f = 0; f < 2; ++f) slot(kb, f) = reg_ldw(rb, seg + (int)(f * KB + kb + D) * 64);
+    } else if (kb == KB - 4 && next_seg >= 0) {
 #pragma unroll
-      for (int f = 0; f < NNFT; ++f) st0.w[f] = nl[(size_t)(f * NKB) * 64];
+      for (int f = 0; f < NNFT; ++f) st0.w[f] = reg_ldw(rb, next_seg + (int)(f * NKB) * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -198,13 +194,13 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
   const float* const srow = a.save + grow_off;
   const uint16_t* const mrow = a.masks + ((size_t)(a.tile0 + (m0 >> 6)) * 4 + ((m0 >> 5) & 1)) * 256 + h * 32 + j;
   const size_t MKS = (size_t)a.tiles_tot * 4 * 256;
-  const float4* wp = a.wp;
+  const RegBuf rb = reg_buf(a.wp, threadIdx.x);  // (64-thread workgroups: threadIdx.x is the lane)
   constexpr int L256 = 8 * 32 * 64;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   WStageB<8> st0;
 #pragma unroll
-  for (int f = 0; f < 8; ++f) st0.w[f] = (wp + seg_off4(SEG_T_FOLD) + lane)[(size_t)(f * 16) * 64];
+  for (int f = 0; f < 8; ++f) st0.w[f] = reg_ldw(rb, seg_off4(SEG_T_FOLD) + (f * 16) * 64);
   auto mlayer = [&](int layer) { return mrow + (size_t)layer * MKS; };
   unsigned mfirst = mask_word(mlayer(7), 0);  // first masked layer of the chain; every later word is fetched a tile ahead
 
@@ -271,40 +267,40 @@ __global__ __launch_bounds__(64, 1) void k_field_bwd_reg(const FieldBwdArgs a) {
 #pragma unroll
     for (int f = 0; f < 8; ++f) B[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[f * 32 + j], dsb, zero, 0, 0, 0);
   }
-  reg_layer_bwd<16, 8, 32, 8, false, false>(wp + seg_off4(SEG_T_FOLD), wp + seg_off4(SEG_T_L7), lane, D0, B, st0, nullptr, nullptr, mfirst,
-                                            grow + G_D * MS);
+  reg_layer_bwd<16, 8, 32, 8, false, false>(seg_off4(SEG_T_FOLD), seg_off4(SEG_T_L7), lane, D0, B, st0, nullptr, nullptr, mfirst,
+                                            grow + G_D * MS, rb);
   BSTAMP(1);  // dir_info + point_info folded, sigma head (520 MFMAs)
   BSTAMP(2);
   // ---- layers 7, 6, 5: input = raw d h_l masked by h_l > 0 (= dpre_l, stored), output = raw d h_{l-1}
-  const float4* const sT7 = wp + seg_off4(SEG_T_L7);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7, sT7 + L256, lane, B, A, st0, mlayer(7), mlayer(6), mfirst, grow + 7 * MS);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + L256, sT7 + 2 * L256, lane, A, B, st0, mlayer(6), mlayer(5), mfirst, grow + 6 * MS);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + 2 * L256, wp + seg_off4(SEG_T_L4A), lane, B, A, st0, mlayer(5), mlayer(4), mfirst, grow + 5 * MS);
+  constexpr int sT7 = seg_off4(SEG_T_L7);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7, sT7 + L256, lane, B, A, st0, mlayer(7), mlayer(6), mfirst, grow + 7 * MS, rb);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + L256, sT7 + 2 * L256, lane, A, B, st0, mlayer(6), mlayer(5), mfirst, grow + 6 * MS, rb);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT7 + 2 * L256, seg_off4(SEG_T_L4A), lane, B, A, st0, mlayer(5), mlayer(4), mfirst, grow + 5 * MS, rb);
   BSTAMP(3);  // layers 7..5 (3,072 MFMAs)
   // ---- layer 4 (input cat(h3, gamma_p)): d h3, and for the fine pass d gamma_p through the skip connection
   f32x16 accg[2];
   if (FINE) {
-    reg_layer_bwd<32, 8, 32, 2, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L4B), lane, A, B, st0, mlayer(4), mlayer(4), mfirst, grow + 4 * MS);
-    reg_layer_bwd_thin<32, 32, 8, true, false, true>(wp + seg_off4(SEG_T_L4B), wp + seg_off4(SEG_T_L3), lane, A, accg, st0, mlayer(4), mlayer(3), mfirst, nullptr);
+    reg_layer_bwd<32, 8, 32, 2, true, true>(seg_off4(SEG_T_L4A), seg_off4(SEG_T_L4B), lane, A, B, st0, mlayer(4), mlayer(4), mfirst, grow + 4 * MS, rb);
+    reg_layer_bwd_thin<32, 32, 8, true, false, true>(seg_off4(SEG_T_L4B), seg_off4(SEG_T_L3), lane, A, accg, st0, mlayer(4), mlayer(3), mfirst, nullptr, rb);
   } else {
-    reg_layer_bwd<32, 8, 32, 8, true, true>(wp + seg_off4(SEG_T_L4A), wp + seg_off4(SEG_T_L3), lane, A, B, st0, mlayer(4), mlayer(3), mfirst, grow + 4 * MS);
+    reg_layer_bwd<32, 8, 32, 8, true, true>(seg_off4(SEG_T_L4A), seg_off4(SEG_T_L3), lane, A, B, st0, mlayer(4), mlayer(3), mfirst, grow + 4 * MS, rb);
   }
   BSTAMP(4);  // layer 4 (1,024 / 1,280 MFMAs)
   // ---- layers 3, 2, 1
-  const float4* const sT3 = wp + seg_off4(SEG_T_L3);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3, sT3 + L256, lane, B, A, st0, mlayer(3), mlayer(2), mfirst, grow + 3 * MS);
-  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3 + L256, sT3 + 2 * L256, lane, A, B, st0, mlayer(2), mlayer(1), mfirst, grow + 2 * MS);
+  constexpr int sT3 = seg_off4(SEG_T_L3);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3, sT3 + L256, lane, B, A, st0, mlayer(3), mlayer(2), mfirst, grow + 3 * MS, rb);
+  reg_layer_bwd<32, 8, 32, 8, true, true>(sT3 + L256, sT3 + 2 * L256, lane, A, B, st0, mlayer(2), mlayer(1), mfirst, grow + 2 * MS, rb);
   unsigned mb0[8];  // coarse pass: the eight mask words of layer 0 for the epilogue, requested a whole layer ahead
   if (!FINE) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) mb0[t] = mask_word(mlayer(0), t);
   }
-  reg_layer_bwd<32, 8, 32, 2, true, true, true, FINE>(sT3 + 2 * L256, FINE ? wp + seg_off4(SEG_T_L0) : nullptr, lane, B, A, st0, mlayer(1),
-                                                      mlayer(0), mfirst, grow + 1 * MS);
+  reg_layer_bwd<32, 8, 32, 2, true, true, true, FINE>(sT3 + 2 * L256, FINE ? seg_off4(SEG_T_L0) : -1, lane, B, A, st0, mlayer(1),
+                                                      mlayer(0), mfirst, grow + 1 * MS, rb);
   BSTAMP(5);  // layers 3..1 (3,072 MFMAs)
   // ---- dpre_0 = d h0 masked; fine: d gamma_p += W_0^T dpre_0
   if (FINE) {
-    reg_layer_bwd_thin<32, 32, 2, false, true, false>(wp + seg_off4(SEG_T_L0), nullptr, lane, A, accg, st0, mlayer(0), nullptr, mfirst, grow);
+    reg_layer_bwd_thin<32, 32, 2, false, true, false>(seg_off4(SEG_T_L0), -1, lane, A, accg, st0, mlayer(0), nullptr, mfirst, grow, rb);
     // gamma -> point -> depth.  accg[t][4g + 2e], [.. + 1] = d loss / d (sin, cos) of pair pi = 4(4t+g) + 2h + e.
     // d gamma / d x needs (cos, -sin) of the same phases: they ARE the saved layer-0 input (tensor S_GP: this lane's eight
     // 16-byte groups hold exactly its pairs), so they are loaded, not recomputed -- 8 loads instead of ~15 sincos with their

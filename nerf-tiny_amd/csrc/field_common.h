@@ -19,6 +19,31 @@ __device__ __forceinline__ void store_row4(float* dst, const float4& v) {
 #endif
 }
 
+// Weight-fragment loads of the register-streaming kernels (field_fwd_reg.hip, field_bwd_reg.hip) as BUFFER loads: address = resource
+// base (the packed image: 4 SGPRs) + this lane's 16 bytes (ONE VGPR for the whole kernel) + the fragment's byte offset as the
+// instruction's scalar offset.  No vector address arithmetic at all -- with `global_load` the compiler formed a new 64-bit vector address
+// (v_add_co + v_addc, their hazard nops, a dependent load) for every ~4 fragments, 1,080 VALU instructions per 32-sample tile, and on
+// this chip every VALU instruction between fp32 MFMAs is matrix time: the inference kernel went from 2.98 to 2.83 ms per launch (-5 %).
+// The compiler still sees loads, so its counted `s_waitcnt vmcnt` stay.
+typedef unsigned rb_u32x4 __attribute__((ext_vector_type(4)));
+struct RegBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int lane16;
+};
+__device__ __forceinline__ RegBuf reg_buf(const float4* wp, int lane) {
+  return RegBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wp), 0, PACKED_ALL_F4 * 16, 0x00020000), lane * 16};
+}
+// 16 bytes per lane at float4 index `f4` of the packed image (wave-uniform: segment offset + fragment * 64; a literal wherever the
+// stream is unrolled).  An int on purpose: with pointers the compiler lost the uniformity of the difference in one kernel and wrapped
+// every load in a waterfall loop.
+__device__ __forceinline__ float4 reg_ldw(const RegBuf& rb, int f4) {
+  int soff = __builtin_amdgcn_readfirstlane(f4 * 16);  // (a literal almost everywhere; where the compiler keeps a loop counter in a VGPR: one v_readfirstlane)
+  asm("" : "+s"(soff));  // stays a scalar operand: left alone the compiler folds the literal into the VECTOR offset (an add per
+  //                                 fragment again) or, worse, moves the lane part to the scalar side behind a waterfall loop
+  const rb_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb.rsrc, rb.lane16, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // ------------------------------------------------------------------------------------------
 // building blocks of the fused kernels
 // ------------------------------------------------------------------------------------------

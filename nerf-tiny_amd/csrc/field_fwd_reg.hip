@@ -56,12 +56,10 @@ struct SaveIn {
 };
 
 template <int KB, int NFT, int NKB, int NNFT, bool ZERO_INIT, bool RELU_IN, bool SAVE = false>
-__device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const float4* __restrict__ next_seg, int lane,
+__device__ __forceinline__ void reg_layer(const int seg, const int next_seg /* float4 offsets into the packed image; < 0: none */, int lane,
                                           const f32x16* prev, f32x16* acc, WStage<8>& st0, const float* bv,
-                                          const SaveIn sv = SaveIn{nullptr, nullptr}) {
+                                          const SaveIn sv, const RegBuf& rb) {
   constexpr int KT = KB / 4;
-  const float4* sl = seg + lane;
-  const float4* nl = next_seg + lane;
   WStage<8> st1;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (bv != nullptr) {  // accumulators start at the bias (same rounding order as ATen's addmm and as k_field_fwd)
@@ -96,10 +94,10 @@ __device__ __forceinline__ void reg_layer(const float4* __restrict__ seg, const 
     const WStage<8>& cur = (kb & 1) ? st1 : st0;
     if (kb + 1 < KB) {
 #pragma unroll
-      for (int f = 0; f < NFT; ++f) ld.w[f] = sl[(size_t)(f * KB + kb + 1) * 64];
-    } else if (next_seg != nullptr) {
+      for (int f = 0; f < NFT; ++f) ld.w[f] = reg_ldw(rb, seg + (f * KB + kb + 1) * 64);
+    } else if (next_seg >= 0) {
 #pragma unroll
-      for (int f = 0; f < NNFT; ++f) ld.w[f] = nl[(size_t)(f * NKB) * 64];
+      for (int f = 0; f < NNFT; ++f) ld.w[f] = reg_ldw(rb, next_seg + (f * NKB) * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
     if ((kb & 3) == 2 && (kb >> 2) + 1 < KT) activate((kb >> 2) + 1);  // next input tile, behind this k-block's MFMAs
@@ -152,6 +150,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   const int ray = mc / a.N;
   const float* rf = a.rayf + (size_t)ray * RAYF;
   const float4* wp = a.wp;
+  const RegBuf rb = reg_buf(a.wp, threadIdx.x);  // (64-thread workgroups: threadIdx.x is the lane)
 
   // first fragments of layer 0 are requested before anything else
   WStage<8> st0;
@@ -210,34 +209,34 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
   // two accumulator sets ping-pong: a layer reads the previous layer's raw accumulators (ReLU applied lazily)
   f32x16 A[8], B[8];
   constexpr int L256 = 8 * 32 * 64;  // float4 per 256x256 segment
-  const float4* const sL1 = wp + seg_off4(SEG_L1);
-  const float4* const sL5 = wp + seg_off4(SEG_L5);
+  constexpr int sL1 = seg_off4(SEG_L1);
+  constexpr int sL5 = seg_off4(SEG_L5);
   float bv[8];
 
   // ---- layer 0: gamma_p 60(64) -> 256
   bias_load<8>(a.w.p[B_L0], lane, bv);
-  reg_layer<8, 8, 32, 8, true, false, SAVE>(wp + seg_off4(SEG_L0), sL1, lane, gp, A, st0, bv, sv_rows(S_GP));
+  reg_layer<8, 8, 32, 8, true, false, SAVE>(seg_off4(SEG_L0), sL1, lane, gp, A, st0, bv, sv_rows(S_GP), rb);
   RSTAMP(1);  // layer 0 (264 MFMAs)
   // ---- layers 1..3 (the segment after L3 is L4A: same shape)
   bias_load<8>(a.w.p[3], lane, bv);
-  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1, sL1 + L256, lane, A, B, st0, bv, sv_relu(0));
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1, sL1 + L256, lane, A, B, st0, bv, sv_relu(0), rb);
   bias_load<8>(a.w.p[5], lane, bv);
-  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1 + L256, sL1 + 2 * L256, lane, B, A, st0, bv, sv_relu(1));
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1 + L256, sL1 + 2 * L256, lane, B, A, st0, bv, sv_relu(1), rb);
   bias_load<8>(a.w.p[7], lane, bv);
-  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1 + 2 * L256, wp + seg_off4(SEG_L4A), lane, A, B, st0, bv, sv_relu(2));
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL1 + 2 * L256, seg_off4(SEG_L4A), lane, A, B, st0, bv, sv_relu(2), rb);
   RSTAMP(2);  // layers 1..3 (3,096 MFMAs)
   // ---- layer 4: cat(h3, gamma_p), hidden first (nerf.py:109)
   bias_load<8>(a.w.p[9], lane, bv);
-  reg_layer<32, 8, 8, 8, true, true, SAVE>(wp + seg_off4(SEG_L4A), wp + seg_off4(SEG_L4B), lane, B, A, st0, bv, sv_relu(3));
-  reg_layer<8, 8, 32, 8, false, false>(wp + seg_off4(SEG_L4B), sL5, lane, gp, A, st0, nullptr);
+  reg_layer<32, 8, 8, 8, true, true, SAVE>(seg_off4(SEG_L4A), seg_off4(SEG_L4B), lane, B, A, st0, bv, sv_relu(3), rb);
+  reg_layer<8, 8, 32, 8, false, false>(seg_off4(SEG_L4B), sL5, lane, gp, A, st0, nullptr, SaveIn{nullptr, nullptr}, rb);
   RSTAMP(3);  // layer 4 (1,288 MFMAs)
   // ---- layers 5..7 (the segment after L7 is the folded point_info / dir_info layer: 4 tiles)
   bias_load<8>(a.w.p[11], lane, bv);
-  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5, sL5 + L256, lane, A, B, st0, bv, sv_relu(4));
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5, sL5 + L256, lane, A, B, st0, bv, sv_relu(4), rb);
   bias_load<8>(a.w.p[13], lane, bv);
-  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + L256, sL5 + 2 * L256, lane, B, A, st0, bv, sv_relu(5));
+  reg_layer<32, 8, 32, 8, true, true, SAVE>(sL5 + L256, sL5 + 2 * L256, lane, B, A, st0, bv, sv_relu(5), rb);
   bias_load<8>(a.w.p[15], lane, bv);
-  reg_layer<32, 8, 32, 4, true, true, SAVE>(sL5 + 2 * L256, wp + seg_off4(SEG_FOLD), lane, A, B, st0, bv, sv_relu(6));
+  reg_layer<32, 8, 32, 4, true, true, SAVE>(sL5 + 2 * L256, seg_off4(SEG_FOLD), lane, A, B, st0, bv, sv_relu(6), rb);
   RSTAMP(4);  // layers 5..7 (3,096 MFMAs)
   // ---- sigma head on h7 = relu(B) (VALU): sigma = |w_sigma . h7 + b|  (nerf.py:94, 115)
   {
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(64, 1) void k_field_fwd_reg(const FieldArgs a) {
         A[f][4 * g + 3] = q.w;
       }
   }
-  reg_layer<32, 4, 32, 4, false, true, SAVE>(wp + seg_off4(SEG_FOLD), nullptr, lane, B, A, st0, nullptr, sv_relu(7));
+  reg_layer<32, 4, 32, 4, false, true, SAVE>(seg_off4(SEG_FOLD), -1, lane, B, A, st0, nullptr, sv_relu(7), rb);
   RSTAMP(6);  // point_info + dir_info folded (512 MFMAs)
   // ---- colour head (VALU): rgb = sigmoid(W_c relu(.) + b)  (nerf.py:99, 119)
   {
