@@ -45,6 +45,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md chip tabl
 PEAK_BF16_MFMA_TFLOPS = 2500.0                   # same table: bf16 matrix, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
 N_PARAMS = 593_924
+RING_ALLREDUCE_MS_ESTIMATE = 0.060  # 30-60 us for the un-overlapped 2.27 MiB SUM all-reduce on an 8-GPU xGMI ring (upper end)
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -305,19 +306,26 @@ def rooflines(leg, prof, b_local, steps):
     def scaled(t):  # the PMC passes ran at 4096 rays per step; a smaller batch of this run moves proportionally less (the slabs aside)
         return None if t is None else int(t * b_local / B)
 
-    def mfma(kernel, keys, flop_per_launch, traffic_keys):
+    def mfma(kernel, keys, flop_per_launch, traffic_keys, exec_frac):
+        """`achieved` / `frac` are the HARDWARE side: the FLOPs the kernel EXECUTES (the folded network) per second against the
+        dense MFMA peak -- what the MFMA-busy counter corroborates and what can never exceed 1.  The reference graph's algorithmic FLOPs
+        (`flop_per_launch_algorithmic`) over the same time are carried beside it as `achieved_algorithmic` / `frac_algorithmic`
+        (= frac / executed_flop_frac; above 1 where the fold removes more work than the kernel loses to its roof)."""
         ms = sum(prof.get(k, (0.0, 0))[0] for k in keys)
         n = sum(prof.get(k, (0.0, 0))[1] for k in keys)
         avg = ms / max(n, 1)
-        ach = flop_per_launch / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+        alg = flop_per_launch / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+        ach = alg * exec_frac
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": scaled(read_traffic(leg, traffic_keys)), "traffic_source": src, "kernel": kernel, "avg_launch_ms": round(avg, 4),
-                "launches": n, "flop_per_launch": flop_per_launch}
+                "launches": n, "flop_per_launch": int(round(flop_per_launch * exec_frac)), "flop_per_launch_algorithmic": flop_per_launch,
+                "executed_flop_frac": round(exec_frac, 4), "achieved_algorithmic": round(alg, 2), "frac_algorithmic": round(alg / peak, 4)}
 
     # dominant forward kernel: launched twice per step (coarse pass B*Nc samples, fine pass B*Nf samples); "launch" = the
-    # average launch, so that rocprofv3's per-kernel average is directly comparable.  `achieved` counts the ALGORITHMIC FLOPs of the
-    # reference's network (1,182,976 per sample); the kernels EXECUTE 8/9 of them: point_info is folded into dir_info
-    # (one 128 x 256 layer instead of 256 x 256 + 128 x 256) -- `executed_flop_frac` says so.
+    # average launch, so that rocprofv3's per-kernel average is directly comparable.  `achieved` / `frac` count the FLOPs the kernels
+    # EXECUTE -- 8/9 of the reference network's 1,182,976 per sample (SURVEY.md 8d): point_info is folded into dir_info (one 128 x 256
+    # layer instead of 256 x 256 + 128 x 256, DESIGN.md section 3a) -- so `frac` is a hardware fraction (<= 1); the reference graph's
+    # FLOPs over the same time are `achieved_algorithmic` / `frac_algorithmic`.
     if getattr(leg, "split", False):
         # split-fp32 inference: the fp32 MLP on the bf16 pipe, THREE bf16 MFMAs (hi*hi, hi*mid, mid*hi) per fp32 product.  Roofline = the
         # bf16 MFMA peak against the bf16 FLOPs the kernel executes (3 x the executed fp32 ones); the algorithmic fp32 figure beside it
@@ -339,19 +347,17 @@ def rooflines(leg, prof, b_local, steps):
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
     fwd_key = (["k_field_fwd_bf16<true>"] if leg.train else ["k_field_fwd_bf16x<2, 8>"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
     fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
-               FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key)
-    fwd["executed_flop_frac"] = round(EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE, 4)
-    fwd["achieved_executed"] = round(fwd["achieved"] * EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE, 2)
-    fwd["frac_executed"] = round(fwd["frac"] * EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE, 4)
-    fwd["note"] = ("achieved / frac count the ALGORITHMIC FLOPs of the reference's network (SURVEY.md 8d); the kernel executes 8/9 of them "
-                   "(point_info folded into dir_info, DESIGN.md 3a): achieved_executed / frac_executed are the MFMA pipe's side, the figure the "
-                   "MFMA-busy counter corroborates")
+               FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)
+    fwd["note"] = ("achieved / frac count the FLOPs the kernel EXECUTES (8/9 of the reference network's: point_info folded into dir_info, "
+                   "DESIGN.md 3a) -- the MFMA pipe's side, the figure the MFMA-busy counter corroborates; achieved_algorithmic / frac_algorithmic "
+                   "price the reference graph's FLOPs (SURVEY.md 8d) over the same time")
     if not leg.train:
         return fwd, None
     sfx = "bf16" if leg.bf16 else "reg"
+    chain_exec = 1.0 - 2 * 65536 * (NC + NF) / (CHAIN_FLOP_COARSE * NC + CHAIN_FLOP_FINE * NF)  # the fold removes 65,536 MACs per sample
     chain = mfma(f"k_field_bwd_{sfx} (dX chain; average of the fine- and coarse-pass launches)",
                  ("bwd_field_fine", "bwd_field_coarse"), (CHAIN_FLOP_COARSE * b_local * NC + CHAIN_FLOP_FINE * b_local * NF) // 2,
-                 [f"k_field_bwd_{sfx}<true>", f"k_field_bwd_{sfx}<false>"])
+                 [f"k_field_bwd_{sfx}<true>", f"k_field_bwd_{sfx}<false>"], chain_exec)
     # weight-gradient phase: all dW = G^T X products of one step (same MACs as one forward over all samples) + slab reduces + thin heads
     dw_ms = prof.get("bwd_dw", (0.0, 0))[0] / max(prof.get("bwd_dw", (0.0, 1))[1], 1)
     launches = DW_BF16_LAUNCHES if leg.bf16 else DW_LAUNCHES
@@ -367,18 +373,14 @@ def rooflines(leg, prof, b_local, steps):
               "launches": prof.get("bwd_dw", (0.0, 0))[1], "bytes_per_launch": dw_bytes}
     else:
         flop = FLOP_PER_SAMPLE * b_local * (NC + NF)
-        ach = flop / (dw_ms * 1e-3) / 1e12 if dw_ms > 0 else 0.0
-        dw = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+        ex = EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE
+        alg = flop / (dw_ms * 1e-3) / 1e12 if dw_ms > 0 else 0.0
+        dw = {"bound": "mfma", "achieved": round(alg * ex, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg * ex / peak, 4),
               "traffic": dw_traffic, "traffic_source": dw_src,
               "kernel": "k_dw4_group / k_dw4 / k_dw_thin / k_dw_reduce / k_fold_grads / k_dir_* (all weight-gradient products of one step incl. the reduce and the thin colour head = one 'launch')",
-              "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "flop_per_launch": flop}
-    # executed / algorithmic FLOPs of the other two phases (the fold removes 65,536 MACs per sample from each: DESIGN.md 3a)
-    chain_exec = 1.0 - 2 * 65536 * (NC + NF) / (CHAIN_FLOP_COARSE * NC + CHAIN_FLOP_FINE * NF)
-    for blk, ex in ((chain, chain_exec), (dw, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)):
-        blk["executed_flop_frac"] = round(ex, 4)
-        if blk["bound"] == "mfma":
-            blk["achieved_executed"] = round(blk["achieved"] * ex, 2)
-            blk["frac_executed"] = round(blk["frac"] * ex, 4)
+              "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "flop_per_launch": int(round(flop * ex)),
+              "flop_per_launch_algorithmic": flop, "executed_flop_frac": round(ex, 4), "achieved_algorithmic": round(alg, 2),
+              "frac_algorithmic": round(alg / peak, 4)}
     # which roof binds a phase: its measured HBM bytes per launch (PMC, committed) over THIS run's launch time against 8 TB/s, next to
     # the MFMA fraction -- the bf16 training kernels move 2-3 GB per launch and sit closer to the HBM roof than to the matrix one
     for blk in (fwd, chain, dw):
@@ -454,6 +456,7 @@ def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong)
            "dtype": "bf16" if leg.bf16 else ("f32 (bf16 hi+mid split operands, fp32 accumulate)" if getattr(leg, "split", False) else "f32"), "roofline": roof,
            "whole_path_tflops_per_gpu": round(value / world * flop_ray / 1e12, 2),
            "whole_path_frac_of_mfma_peak": round(value / world * flop_ray / 1e12 / (PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS), 4),  # (split leg: of the FP32 peak, i.e. > 1)
+           "whole_path_note": "whole_path_* price the ALGORITHMIC FLOPs of the reference graph (SURVEY.md 8d) over the whole step; x 8/9 for the executed side",
            "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in prof.items()}}
     if phases is not None:
         rep["roofline_phases"] = phases
@@ -645,7 +648,8 @@ def main():
 
     def brief(r, rays_per_step):
         return {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "kernel_ms_per_step", "allreduce_ms") if k in r} | {
-            "rays_per_step": rays_per_step, "roofline_frac": r["roofline"]["frac"], "whole_path_frac_of_mfma_peak": r["whole_path_frac_of_mfma_peak"]}
+            "rays_per_step": rays_per_step, "roofline_frac": r["roofline"]["frac"], "roofline_frac_algorithmic": r["roofline"].get("frac_algorithmic"),
+            "whole_path_frac_of_mfma_peak": r["whole_path_frac_of_mfma_peak"]}
 
     # ---- N > 1: the STRONG-scaling form of the same legs in the same line (north_star: ">= 6x strong scaling to 8 GPUs"): ONE 4096-ray
     # batch (the same on every rank) split into contiguous slices of 4096 / N rays, the global ray 0's spacing forwarded, one flat SUM
@@ -706,10 +710,20 @@ def main():
         except Exception as ex:  # no RCCL on this box: the proxy then carries no collective
             print(f"bench.py: single-rank RCCL all-reduce not measured: {ex}", file=sys.stderr)
         proxy["allreduce_ms_single_rank"] = None if ar1 is None else round(ar1, 4)
-        proxy["implied_strong_scaling_8"] = {
-            name: round(t_full[name] / (proxy["512"][name]["ms_per_step"] + ((ar1 or 0.0) if train else 0.0)), 2) for name, train, _, _, _ in legs}
-        proxy["note"] = ("t(4096 rays) / (t(512 rays) + single-rank all-reduce for the train legs), all measured in this run on one GPU; "
-                         "the 8-GPU number itself is extra.strong_* of the driver's N = 8 line")
+        def implied(ar_ms):
+            return {name: round(t_full[name] / (proxy["512"][name]["ms_per_step"] + (ar_ms if train else 0.0)), 2) for name, train, _, _, _ in legs}
+
+        # UPPER BOUND: the collective of this figure is a single-rank RCCL all-reduce (launch + kernel, no xGMI hop, no straggler)
+        proxy["implied_strong_scaling_8"] = implied(ar1 or 0.0)
+        # ... and with an 8-rank ring's latency in its place.  Not measured (no 8-GPU node was available to any round so far): SURVEY.md 8e
+        # prices the un-overlapped 2.27 MiB SUM all-reduce at 30-60 us (latency-bound: 7 xGMI hops x 2 phases; the bytes are 15 us of one
+        # link); the upper end is used, all of it exposed although the overlap (nerf_hip_backward_overlap) hides the early 83 % part's share
+        proxy["ring_allreduce_ms_estimate"] = RING_ALLREDUCE_MS_ESTIMATE
+        proxy["implied_strong_scaling_8_with_ring_estimate"] = implied(RING_ALLREDUCE_MS_ESTIMATE)
+        proxy["note"] = ("implied_strong_scaling_8 = t(4096 rays) / (t(512 rays) + single-rank all-reduce for the train legs), all measured in this run on "
+                         "one GPU: an UPPER BOUND (no xGMI hops, no straggler).  implied_strong_scaling_8_with_ring_estimate puts a documented "
+                         f"{RING_ALLREDUCE_MS_ESTIMATE * 1e3:.0f} us estimate of the exposed 8-rank ring all-reduce (SURVEY.md 8e) in its place; the 8-GPU "
+                         "number itself is extra.strong_* of the driver's N = 8 line")
 
     # ---- parity of the timed configuration, in the line: the reference's OWN outputs for cfg2 (tests/golden/cfg2_lego_rand4096.npz: inputs,
     # weight seed and the C_coarse / C_fine the reference returned in the build container) against this library's render of the same
@@ -749,7 +763,8 @@ def main():
                 out["frame_render"] = {"error": str(ex)}
         if proxy is not None:
             out["per_rank_proxy"] = proxy
-            out["implied_strong_scaling_8"] = proxy["implied_strong_scaling_8"]
+            out["implied_strong_scaling_8"] = proxy["implied_strong_scaling_8"]  # upper bound: see per_rank_proxy.note
+            out["implied_strong_scaling_8_with_ring_estimate"] = proxy["implied_strong_scaling_8_with_ring_estimate"]
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             out["cpu_baseline"] = cb

@@ -10,7 +10,7 @@
  * Conventions
  *   - plain C: pointers + sizes, no torch / HIP C++ types.  `stream` is a hipStream_t passed
  *     as void* (NULL = default stream).  Every call only ENQUEUES work on `stream`; no call
- *     synchronises with the host except nerf_hip_read_status().
+ *     synchronises with the host except nerf_hip_read_status() / nerf_hip_read_status_sticky().
  *   - ownership: the caller allocates every buffer (device unless marked HOST) including the
  *     workspace; the library allocates nothing persistent and frees nothing.
  *   - errors: 0 = NERF_HIP_OK, negative = error; nerf_hip_last_error() gives the text
@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 3 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap, NERF_HIP_SPLIT_MLP */
+#define NERF_HIP_ABI_VERSION 4 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap, NERF_HIP_SPLIT_MLP;
+                                  4: nerf_hip_read_status_sticky */
 
 enum {
   NERF_HIP_OK = 0,
@@ -139,6 +140,13 @@ int nerf_hip_ray_loss(const float* C_coarse, const float* C_fine, const float* C
 
 /* Copies the status word of the last forward on this workspace to the host (synchronises `stream`). */
 int nerf_hip_read_status(const void* ws, size_t ws_bytes, uint32_t* status, void* stream);
+
+/* The STICKY status word: every forward ORs the bits of its status word into it as well and no library call clears it, so a train loop
+ * that looks at the status only every k-th iteration (one host sync) still sees a condition any iteration in between met -- the reference
+ * checks its resampling indices in EVERY forward (nerf.py:251-253).  The caller zeroes the first 256 bytes of a fresh workspace once
+ * (the library allocates nothing and cannot know a fresh workspace from a used one); clear != 0 resets the word after reading it.
+ * Synchronises `stream`. */
+int nerf_hip_read_status_sticky(void* ws, size_t ws_bytes, uint32_t* status, int clear, void* stream);
 
 /*
  * Optional per-kernel timing with HIP events recorded on the caller's stream around every kernel the

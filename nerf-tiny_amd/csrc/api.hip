@@ -340,6 +340,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   if (ray0_near_far) { ca.ray0_override = 1; ca.near0 = ray0_near_far[0]; ca.far0 = ray0_near_far[1]; }
   ca.w_c = at<float>(ws, L.w_c); ca.C_coarse = C_coarse; ca.t_f = at<float>(ws, L.t_f);
   ca.status = at<uint32_t>(ws, L.status);
+  ca.sticky = at<uint32_t>(ws, L.status) + STATUS_STICKY_WORD;
   { ProfScope ps(NERF_HIP_K_COARSE, st, &pc); HIP_TRY(launch_coarse(ca, st)); }
 
   // fine pass (nerf.py:299), same network (quirk Q10)
@@ -615,6 +616,16 @@ int nerf_hip_read_status(const void* ws, size_t ws_bytes, uint32_t* status, void
   if (!ws || !status || ws_bytes < 256) return fail(NERF_HIP_ERR_ARG, "null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(status, ws, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return NERF_HIP_OK;
+}
+
+int nerf_hip_read_status_sticky(void* ws, size_t ws_bytes, uint32_t* status, int clear, void* stream) {
+  if (!ws || !status || ws_bytes < 256) return fail(NERF_HIP_ERR_ARG, "null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint32_t* word = static_cast<uint32_t*>(ws) + STATUS_STICKY_WORD;
+  HIP_TRY(hipMemcpyAsync(status, word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  if (clear) HIP_TRY(hipMemsetAsync(word, 0, sizeof(uint32_t), st));
   HIP_TRY(hipStreamSynchronize(st));
   return NERF_HIP_OK;
 }

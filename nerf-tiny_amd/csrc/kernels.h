@@ -74,7 +74,7 @@ struct RaysArgs {
   float* t_c;        // [B][Nc] or null
   float* d_cam;      // [B][3] or null
   float* d_wrd;      // [B][3] or null
-  unsigned* status;  // the workspace's 64 status words, zeroed here (first kernel of a forward), or null
+  unsigned* status;  // the workspace's status words [0, STATUS_STICKY_WORD) are zeroed here (first kernel of a forward), or null
 };
 
 struct CoarseArgs {
@@ -92,6 +92,7 @@ struct CoarseArgs {
   float* C_coarse;      // [B][3]
   float* t_f;           // [B][Nf]
   uint32_t* status;
+  uint32_t* sticky;     // or null: a second word that gets the same bits and that no kernel ever clears (nerf_hip_read_status_sticky)
 };
 
 struct MergeArgs {

@@ -47,7 +47,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(128) void k_rays(const RaysArgs a) {
   __shared__ float gd[DIR_DIM];
   const int ray = blockIdx.x, tid = threadIdx.x;
-  if (a.status && ray == 0 && tid < 64) a.status[tid] = 0u;  // the forward's status words start clean (instead of a memset node of their own)
+  if (a.status && ray == 0 && tid < STATUS_STICKY_WORD) a.status[tid] = 0u;  // the forward's status words start clean (instead of a memset node of their own); the sticky ones stay
   const float* pb = a.pb + (size_t)ray * 17;
   // x <- row, y <- column (quirk Q2)
   const float x = (float)a.row[ray], y = (float)a.col[ray];
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void k_coarse(const CoarseArgs a) {
     if (live) a.t_f[(size_t)ray * a.Nf + j] = tf;
   }
   if (live && bad && a.status) atomicOr(a.status, 1u);
+  if (live && bad && a.sticky) atomicOr(a.sticky, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -204,10 +204,34 @@ class DeviceRays:
                                                    pb.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         return row, col, pix, pb, pic
 
+    def epoch_order(self, shuffle: bool = True) -> torch.Tensor:
+        """The pixel order of one epoch (device tensor): ``DataLoader(shuffle=True)``'s permutation, drawn on the device from this
+        sampler's generator -- ranks that were built with the same seed draw the same order."""
+        if shuffle:
+            return torch.randperm(self.num_pix, device=self.device, generator=self.gen)
+        return torch.arange(self.num_pix, device=self.device)
+
     def epoch(self, batch_ray: int, shuffle: bool = True):
-        order = torch.randperm(self.num_pix, device=self.device, generator=self.gen) if shuffle else torch.arange(self.num_pix, device=self.device)
+        order = self.epoch_order(shuffle)
         for s in range(0, self.num_pix - batch_ray + 1, batch_ray):  # drop_last=True
             yield self.gather(order[s:s + batch_ray])
+
+    def epoch_sharded(self, batch_ray: int, rank: int, world: int, shuffle: bool = True):
+        """One epoch of a data-parallel trainer: every rank draws the SAME order (same seed) and gathers only its contiguous slice
+        [lo, hi) of every global `batch_ray` batch (parallel.shard_bounds).  Yields (row, col, pix_val, poses_bound, pic, ray0) where
+        ray0 = (near, far) of the GLOBAL batch's ray 0 as host floats -- the one cross-ray term of the path (quirk Q6, nerf.py:233); the
+        pictures of all first rays come to the host in ONE copy per epoch, so the loop itself has no host sync."""
+        from .parallel import shard_bounds
+
+        order = self.epoch_order(shuffle)
+        lo, hi = shard_bounds(batch_ray, rank, world)
+        starts = range(0, self.num_pix - batch_ray + 1, batch_ray)  # drop_last=True
+        if len(starts) == 0:
+            return
+        first_pic = (order[0:starts[-1] + 1:batch_ray] // (self.height * self.width)).cpu()
+        nf = self.poses[:, 15:17].cpu()[first_pic]  # [n_batches, 2] fp32, exactly the values the kernels see (nerf.py:338 cast)
+        for b, s in enumerate(starts):
+            yield (*self.gather(order[s + lo:s + hi]), (float(nf[b, 0]), float(nf[b, 1])))
 
     def __len__(self):
         return self.num_pix

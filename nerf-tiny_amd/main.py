@@ -4,6 +4,14 @@ The reference's own main.py cannot run against its shipped configs (SURVEY.md se
 ``trainer()`` is called without its required argument, ``LR_MILESTONE`` is parsed into characters); this driver reads
 the same 17 keys with defaults for the three missing ones, parses the milestone list properly and calls
 ``trainer("train")``.  ``--synthetic`` trains on a procedural scene when the datasets are not on disk.
+
+The 8-GPU job of BASELINE.json cfg3 / cfg5 is the same file under a launcher (one process per GPU, RCCL over xGMI):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        nerf-tiny_amd/main.py --conf lego --synthetic --bf16-mlp
+
+Every rank trains on its contiguous slice of each BATCH_RAY batch (ONE flat SUM all-reduce of the gradients per step), rank 0 logs and
+checkpoints, ``display()`` renders the frames tile-sharded (``NeRFRunner`` docstring).
 """
 import argparse
 import ast
@@ -23,6 +31,8 @@ if __name__ == "__main__":
     ap.add_argument("--synthetic", action="store_true", help="procedural scene instead of IMG_DIR")
     ap.add_argument("--total-iter", type=int, default=None)
     ap.add_argument("--bf16-mlp", action="store_true", help="run the MLP on bf16 MFMA (cfg3; also ini key BF16_MLP = True)")
+    ap.add_argument("--on-resample-fault", choices=["raise", "warn", "ignore"], default=None,
+                    help="what to do when a forward met the reference's exit(0) condition (nerf.py:251-253); default raise, like the reference stops")
     ap.add_argument("--split-mlp", action="store_true", help="render (validation, display) on the split-fp32 inference kernels: same 1e-4 bar, "
                                                              "3x the rate; training is unaffected (also ini key SPLIT_MLP = True)")
     args = ap.parse_args()
@@ -39,6 +49,10 @@ if __name__ == "__main__":
         kw["datasets"] = {"train": scene, "val": scene, "test": scene}
     kw["bf16_mlp"] = args.bf16_mlp or ast.literal_eval(c("BF16_MLP", "False"))
     kw["split_mlp"] = args.split_mlp or ast.literal_eval(c("SPLIT_MLP", "False"))
+    if args.on_resample_fault or c("ON_RESAMPLE_FAULT"):
+        kw["on_resample_fault"] = args.on_resample_fault or c("ON_RESAMPLE_FAULT")
+    # data-parallel: started as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 .../main.py ...`
+    # every rank runs this file; NeRFRunner reads RANK / WORLD_SIZE / LOCAL_RANK from the environment before its first GPU call
     run = P.NeRFRunner(**kw)
     run.trainer("train")
     run.display()

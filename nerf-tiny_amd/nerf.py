@@ -22,6 +22,7 @@ from . import _abi
 device = None
 
 LAST_DELTA = 0.0001  # nerf.py:286
+MIN_CALL_RAYS = 2     # include/nerf_hip.h: 2 <= B (the reference crashes on B = 1, nerf.py:208)
 
 
 class Activation(nn.Module):
@@ -125,7 +126,8 @@ class _RenderFn(torch.autograd.Function):
                 raise RuntimeError("model.grad_bucket was built for other parameters")
             if bucket.pending:
                 raise RuntimeError("a second backward would overwrite the gradients of the previous one in model.grad_bucket before "
-                                   "they were used: call bucket.allreduce_sum() / the optimizer step (or bucket.consume()) first")
+                                   "they were used: bucket.allreduce_sum(), train.FusedAdam.step() / .zero_grad() release it; after any other "
+                                   "optimizer's step call bucket.consume()")
             bucket.pending = True
             grads = bucket.views
         else:
@@ -196,6 +198,7 @@ class NeRFModel(nn.Module):
             n = _abi.ws_bytes(B, self.num_coarse, self.num_fine, flags)
             ws = torch.empty(n, dtype=torch.uint8, device=dev)
             assert ws.data_ptr() % 256 == 0
+            ws[:256].zero_()  # the status region: its sticky word is the caller's to initialise (nerf_hip_read_status_sticky)
             self._ws[flags] = slot = (key, ws)
             self._packed = {k for k in self._packed if k[1] != flags}
         return slot[1]
@@ -287,6 +290,18 @@ class NeRFModel(nn.Module):
         _abi.check(_abi.lib().nerf_hip_read_status(ws.data_ptr(), ws.numel(), C.byref(st), torch.cuda.current_stream(ws.device).cuda_stream))
         return bool(st.value & _abi.STATUS_RESAMPLE_INDEX)
 
+    def resample_fault_since(self, clear: bool = True) -> bool:
+        """Did ANY forward on the current workspaces meet that condition since the last call that cleared the record?  The kernels OR the
+        status bits into a sticky word no forward resets (``nerf_hip_read_status_sticky``), so a train loop that looks only at its logging
+        points misses nothing in between -- the reference checks every forward (nerf.py:251-253).  One host sync per workspace."""
+        hit = False
+        for _, ws in self._ws.values():
+            st = C.c_uint32(0)
+            _abi.check(_abi.lib().nerf_hip_read_status_sticky(ws.data_ptr(), ws.numel(), C.byref(st), 1 if clear else 0,
+                                                              torch.cuda.current_stream(ws.device).cuda_stream))
+            hit = hit or bool(st.value & _abi.STATUS_RESAMPLE_INDEX)
+        return hit
+
     @torch.no_grad()
     def render(self, row, column, poses_bound, K_inv, lo: int = 0, hi: int | None = None, fuse_rays: int = 16384):
         """Inference over a LONG list of rays (a frame, a test set) -- rays [lo, hi) of it -- with the reference's batch semantics and few
@@ -309,13 +324,21 @@ class NeRFModel(nn.Module):
         prev_ray0, prev_cap = self.ray0_near_far, self._ws_capacity
         try:
             self._ws_capacity = True
-            self._workspace(max(e - s for s, e, _, _ in plan), _call_flags(self, False))  # ONE workspace, sized for the longest call
+            self._workspace(max(MIN_CALL_RAYS, max(e - s for s, e, _, _ in plan)), _call_flags(self, False))  # ONE workspace, sized for the longest call
             with self.frozen_weights():
                 for s, e, near, far in plan:
                     self.ray0_near_far = (near, far)
-                    c, f = self._launch(ps, row[s:e], column[s:e], poses_bound[s:e], K_inv)
-                    C_c[s - lo:e - lo] = c
-                    C_f[s - lo:e - lo] = f
+                    r_, c_, p_ = row[s:e], column[s:e], poses_bound[s:e]
+                    if e - s < MIN_CALL_RAYS:
+                        # a 1-ray piece (n % batch_ray == 1 behind a batch with another near / far; an unaligned shard that starts on a
+                        # batch's last ray): the library needs B >= 2 like the reference (nerf.py:208 .squeeze()), so the piece is
+                        # launched with its last ray repeated and the copy cropped -- rays are independent and ray0_near_far is handed
+                        # over explicitly, so the real ray's bits do not change
+                        k = MIN_CALL_RAYS - (e - s)
+                        r_, c_, p_ = (torch.cat((x, x[-1:].expand(k, *x.shape[1:]))) for x in (r_, c_, p_))
+                    c, f = self._launch(ps, r_, c_, p_, K_inv)
+                    C_c[s - lo:e - lo] = c[: e - s]
+                    C_f[s - lo:e - lo] = f[: e - s]
         finally:
             self.ray0_near_far, self._ws_capacity = prev_ray0, prev_cap
         return C_c, C_f

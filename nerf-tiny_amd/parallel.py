@@ -12,8 +12,12 @@ ray 0's (near, far) is handed to every shard (`NeRFModel.ray0_near_far`).
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.distributed as dist
+
+_LIVE_BUCKETS = weakref.WeakSet()  # every GradBucket alive in this process (consume_buckets_of)
 
 
 def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
@@ -58,6 +62,7 @@ class GradBucket:
         self.early_numel = offs[EARLY_TENSORS] if len(offs) > EARLY_TENSORS else o
         self.early_event = None   # torch.cuda.Event recorded by the library where the early part is final (enable_overlap)
         self.side_stream = None
+        _LIVE_BUCKETS.add(self)
 
     def enable_overlap(self):
         """Overlap the all-reduce of the early part with the rest of the backward pass: the library records `early_event` on the
@@ -79,7 +84,10 @@ class GradBucket:
 
     def consume(self):
         """The gradients in the views have been used (optimizer step, all-reduce, or deliberately dropped): the next backward may
-        overwrite them.  `allreduce_sum` and `train.FusedAdam.step` call this."""
+        overwrite them.  Called by `allreduce_sum`, and -- through `consume_buckets_of` -- by `train.FusedAdam.step` / `.zero_grad` for
+        every bucket whose views ARE the gradients the optimizer just used, so the plain single-process loop
+        ``model.grad_bucket = bucket; loss.backward(); opt.step()`` needs no extra call.  A foreign optimizer (``torch.optim.Adam``) knows
+        nothing of buckets: call this after its step."""
         self.pending = False
 
     def _foreign(self):
@@ -114,18 +122,30 @@ class GradBucket:
         self.consume()
 
 
-def train_step_sharded(model, bucket: GradBucket, row, col, poses_bound, K_inv, C_true, rank: int, world: int, group=None):
-    """One data-parallel train step on this rank's slice of a GLOBAL batch (every rank passes the same global tensors).
-    `model.batch_ray` must equal the slice size.  Returns this rank's (C_coarse, C_fine, local loss); after the call
-    every rank holds the full-batch gradient in p.grad (sum over ranks; p.grad are views of `bucket.flat`).  The collective
-    sits where the reference has ``loss.backward(); optimizer.step()`` (nerf.py:473-474)."""
-    lo, hi = shard_bounds(row.shape[0], rank, world)
+def consume_buckets_of(params) -> int:
+    """Mark every live GradBucket whose views are the `.grad` of `params` as consumed (the optimizer has used, or zero_grad has dropped,
+    the gradients a backward wrote into it).  Returns the number of buckets touched."""
+    ptrs = {p.grad.data_ptr() for p in params if p.grad is not None}
+    n = 0
+    for b in list(_LIVE_BUCKETS):
+        if any(bp is p for bp, p in zip(b.params, params)) and (not ptrs or any(v.data_ptr() in ptrs for v in b.views)):
+            b.consume()
+            n += 1
+    return n
+
+
+def train_step_local(model, bucket: GradBucket, row, col, poses_bound, K_inv, C_true, ray0, world: int, group=None):
+    """One data-parallel train step on tensors that ARE this rank's slice of the global batch (`NeRFRunner`: the device sampler gathers
+    only the slice; `ray0` = (near, far) of the GLOBAL batch's ray 0, host floats -- quirk Q6).  `model.batch_ray` must equal the slice
+    size.  Forward + loss + backward with the gradients written straight into `bucket`, then ONE flat SUM all-reduce (in two overlapped
+    parts with `bucket.enable_overlap()`), placed where the reference has ``loss.backward(); optimizer.step()`` (nerf.py:473-474).
+    Returns this rank's (C_coarse, C_fine, local loss); every rank then holds the full-batch gradient in p.grad (views of `bucket.flat`)."""
     prev_ray0, prev_bucket = model.ray0_near_far, model.grad_bucket
-    model.ray0_near_far = global_ray0(poses_bound)
+    model.ray0_near_far = ray0
     model.grad_bucket = bucket
     try:
-        C_c, C_f = model(row[lo:hi], col[lo:hi], poses_bound[lo:hi], K_inv)
-        loss = model.ray_loss(C_c, C_f, C_true[lo:hi])
+        C_c, C_f = model(row, col, poses_bound, K_inv)
+        loss = model.ray_loss(C_c, C_f, C_true)
         loss.backward()
     finally:
         model.ray0_near_far, model.grad_bucket = prev_ray0, prev_bucket
@@ -134,6 +154,61 @@ def train_step_sharded(model, bucket: GradBucket, row, col, poses_bound, K_inv, 
     else:
         bucket.consume()  # a single process without a group: p.grad (the views) go straight to the optimizer
     return C_c, C_f, loss
+
+
+def train_step_sharded(model, bucket: GradBucket, row, col, poses_bound, K_inv, C_true, rank: int, world: int, group=None):
+    """`train_step_local` for callers that hold the GLOBAL batch on every rank (every rank passes the same global tensors): this rank's
+    contiguous slice is cut here and the global ray 0's (near, far) read from the global `poses_bound`."""
+    lo, hi = shard_bounds(row.shape[0], rank, world)
+    return train_step_local(model, bucket, row[lo:hi], col[lo:hi], poses_bound[lo:hi], K_inv, C_true[lo:hi], global_ray0(poses_bound),
+                            world, group)
+
+
+class DistEnv:
+    """What a launcher (``python -m torch.distributed.run`` / torchrun) tells a rank, read from the ENVIRONMENT only -- no torch.cuda / HIP
+    call is involved, so it can (and must) be evaluated before anything touches the GPU (MI355X pool rule: nothing re-execs after that)."""
+
+    def __init__(self, rank: int = 0, world: int = 1, local_rank: int = 0, launched: bool = False):
+        self.rank, self.world, self.local_rank, self.launched = rank, world, local_rank, launched
+
+    @classmethod
+    def from_env(cls, env=None):
+        import os
+
+        env = os.environ if env is None else env
+        if "RANK" not in env or "WORLD_SIZE" not in env:
+            return cls()
+        rank, world = int(env["RANK"]), int(env["WORLD_SIZE"])
+        if not 0 <= rank < world:
+            raise ValueError(f"RANK={rank} outside WORLD_SIZE={world}")
+        return cls(rank, world, int(env.get("LOCAL_RANK", rank)), True)
+
+    @property
+    def is_main(self) -> bool:
+        return self.rank == 0
+
+    def __repr__(self):
+        return f"DistEnv(rank={self.rank}, world={self.world}, local_rank={self.local_rank}, launched={self.launched})"
+
+
+def broadcast_parameters(params, src: int = 0, group=None):
+    """Every rank starts from rank `src`'s weights (ONE flat broadcast; replicated weights are what makes the SUM of the slices'
+    gradients the full-batch gradient on every rank)."""
+    params = list(params)
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(flat, src=src, group=group)
+    o = 0
+    with torch.no_grad():
+        for p in params:
+            p.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+
+def allreduce_host_scalars(values, op, device, group=None):
+    """A few host floats through ONE collective (the logging point of the data-parallel loop: loss SUM, fault flag MAX)."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=op, group=group)
+    return t.cpu().tolist()
 
 
 def batch_shard_bounds(n: int, batch: int, rank: int, world: int) -> tuple[int, int]:

@@ -66,7 +66,19 @@ class FusedAdam(torch.optim.Optimizer):
                                                  float(b2), float(g["eps"]), torch.cuda.current_stream(dev).cuda_stream))
         for p in ps:
             self.state[p]["step"] = torch.tensor(float(self._step))
+        # bucket mode (model.grad_bucket: p.grad ARE views of a parallel.GradBucket): the gradients are used up, the next backward may
+        # overwrite them
+        from .parallel import consume_buckets_of
+
+        consume_buckets_of(ps)
         return None
+
+    def zero_grad(self, set_to_none: bool = True):
+        """``Optimizer.zero_grad`` + bucket mode: dropping the gradients also releases the bucket they live in."""
+        from .parallel import consume_buckets_of
+
+        consume_buckets_of(self.param_groups[0]["params"])
+        super().zero_grad(set_to_none=set_to_none)
 
 
 class _NullWriter:
@@ -92,32 +104,75 @@ class NeRFRunner:
     Extra keyword-only arguments: ``datasets`` (dict mode -> dataset, to run without files), ``log_every`` (host sync
     period; the reference syncs every iteration), ``bf16_mlp`` (BASELINE.json cfg3: the MLP on bf16 MFMA, default off), ``split_mlp`` (rendering calls -- validation,
     ``display()`` -- on the split-fp32 inference kernels: same 1e-4 bar, 3x the rate; training forwards ignore it; default off),
-    ``on_resample_fault`` ("warn" | "raise" | "ignore": what to do when a logged iteration meets the reference's exit(0) condition of
-    nerf.py:251-253 -- a training run that has died; the device path itself clamps the index and goes on)."""
+    ``on_resample_fault`` ("raise" | "warn" | "ignore": what to do when ANY iteration since the last logging point met the reference's
+    exit(0) condition of nerf.py:251-253 -- a training run that has died; the kernels record it in a sticky status word, the device path
+    itself clamps the index and goes on.  Default "raise": the reference stops there too), ``distributed`` (None: data-parallel iff a
+    launcher started more than one rank; True: also with one rank -- rehearsals; False: never).
+
+    **Data-parallel training (BASELINE.json cfg3) and tile-sharded rendering (cfg5)**: under ``python -m torch.distributed.run
+    --nproc-per-node N .../main.py`` every rank builds this runner on ``cuda:LOCAL_RANK`` (RANK / WORLD_SIZE / LOCAL_RANK are read from
+    the environment before any GPU call), joins one RCCL group (backend "nccl"), starts from rank 0's weights and draws the SAME
+    permutation from the same sampler seed; of every global ``batch_ray`` batch a rank gathers only its contiguous slice
+    (``parallel.shard_bounds``; the global ray 0's near / far go to every rank: quirk Q6), runs forward + loss + backward with the
+    gradients written straight into one flat bucket, SUM-all-reduces it (the early 83 % beside the last weight-gradient products)
+    where the reference has ``loss.backward(); optimizer.step()`` (nerf.py:473-474) and takes the identical fused-Adam step.  Rank 0
+    alone logs and writes checkpoints; ``display()`` deals the frames' reference batches out over the ranks with no collective in the
+    data path and gathers the pixels afterwards."""
 
     def __init__(self, gpu=0, img_dir="../nerf_synthetic/lego/", results_path="./results/", ckpt_path="./checkpoint/", low_res=1,
                  total_iter=100000, batch_ray=400, learning=1e-3, lr_gamma=0.1, lr_milestone=(10, 200), n_coarse=64, n_fine=128,
                  data_type="sync", step=100, decay_end=200000, sched="EXP", continue_=False, *, datasets=None, log_every=None,
-                 seed=624, bf16_mlp=False, split_mlp=False, on_resample_fault="warn"):
+                 seed=624, bf16_mlp=False, split_mlp=False, on_resample_fault="raise", distributed=None):
         from . import nerf as _nerf
+        from . import parallel as par
 
+        # ---- the launcher's environment first: nothing above this line has touched the GPU
+        self.env = par.DistEnv.from_env()
+        self.distributed = (self.env.world > 1) if distributed is None else bool(distributed)
+        if not self.distributed:
+            self.env = par.DistEnv()  # a stray RANK in the environment of a deliberately single-process run
+        self.rank, self.world = self.env.rank, self.env.world
         if not torch.cuda.is_available():
             raise RuntimeError("NeRFRunner needs a ROCm device: the MI355X path has no CPU fallback")
-        self.device = torch.device("cuda:" + str(gpu))
+        # one process per GPU: under a launcher the rank's device is LOCAL_RANK; the ini's GPU key is the single-process choice
+        self.device = torch.device("cuda:" + str(self.env.local_rank if self.env.launched and self.distributed else gpu))
         _nerf.device = self.device  # module global like nerf.py:387
         torch.cuda.set_device(self.device)
-        self.writer = _writer()
+        self.group = None
+        if self.distributed:
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29500")
+                # "nccl" IS RCCL on ROCm (xGMI).  NERF_DIST_BACKEND=gloo: rehearsals with several ranks on ONE GPU (RCCL refuses two
+                # ranks on one device); gloo moves device tensors through the host, same collectives, same results
+                backend = os.environ.get("NERF_DIST_BACKEND", "nccl")
+                kw_pg = {"device_id": self.device} if backend == "nccl" else {}
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw_pg)
+        self.writer = _writer() if self.rank == 0 else _NullWriter()
         self.start_time = time.strftime("%m-%d-%H-%M-%S", time.localtime())
+        if self.distributed:  # one name for the job's checkpoints / results: rank 0's clock
+            import torch.distributed as dist
+
+            box = [self.start_time]
+            dist.broadcast_object_list(box, src=0)
+            self.start_time = box[0]
         self.results_path, self.ckpt_path, self.low_res = results_path, ckpt_path, low_res
         self.total_iter, self.batch_ray, self.step, self.decay_end = total_iter, batch_ray, step, decay_end
         self.log_every = log_every or step
         if on_resample_fault not in ("warn", "raise", "ignore"):
             raise ValueError("on_resample_fault: 'warn', 'raise' or 'ignore'")
         self.on_resample_fault = on_resample_fault
-        self.resample_fault_iter = None  # first logged iteration at which the reference's exit(0) condition was seen
-        self.model = NeRFModel(num_coarse=n_coarse, num_fine=n_fine, batch_ray=batch_ray).to(self.device)
+        self.resample_fault_iter = None  # first logging point at which the reference's exit(0) condition had been met since the previous one
+        # this rank's slice of every global batch: the model is built for the slice (its kernels see B = local rays)
+        self.lo, self.hi = par.shard_bounds(batch_ray, self.rank, self.world)
+        self.local_rays = self.hi - self.lo
+        if self.local_rays < 2:
+            raise ValueError(f"BATCH_RAY = {batch_ray} over {self.world} ranks leaves rank {self.rank} {self.local_rays} ray(s): the path needs >= 2 per rank")
+        self.model = NeRFModel(num_coarse=n_coarse, num_fine=n_fine, batch_ray=self.local_rays).to(self.device)
 
-        # resume: newest "<anything>_<iter>.pkl" (nerf.py:404-415)
+        # resume: newest "<anything>_<iter>.pkl" (nerf.py:404-415); every rank reads the same file (one node, one filesystem)
         last_iter, last_ckpt = -1, None
         if continue_:
             for f in glob.glob(ckpt_path + "*.pkl"):
@@ -125,10 +180,15 @@ class NeRFRunner:
                 if it > last_iter:
                     last_iter, last_ckpt = it, f
         if last_ckpt is not None:
-            self.model = torch.load(last_ckpt, weights_only=False).to(self.device)
+            self.model = torch.load(last_ckpt, weights_only=False, map_location=self.device).to(self.device)
+            self.model.batch_ray = self.local_rays  # (the checkpoint is rank 0's whole module: its batch size was rank 0's slice)
         self.last_iter = last_iter
         self.model.bf16_mlp = bool(bf16_mlp)  # an attribute, not part of the checkpoint format: set after a resume too
         self.model.split_mlp = bool(split_mlp)
+        self.bucket = None
+        if self.distributed:
+            par.broadcast_parameters(self.model.network.parameters(), src=0)  # replicated weights, whatever each rank's RNG drew
+            self.bucket = par.GradBucket(self.model.network.parameters()).enable_overlap()
 
         def ds(mode):
             if datasets is not None:
@@ -136,6 +196,7 @@ class NeRFRunner:
             return NeRFDataset(root_dir=img_dir, low_res=low_res, transform=None, type=data_type, mode=mode)
 
         self.train_dataset, self.val_dataset, self.disp_dataset = ds("train"), ds("val"), ds("test")
+        # the SAME seeds on every rank: the ranks draw identical permutations and take disjoint slices of every batch
         self.train_rays = DeviceRays(self.train_dataset, self.device, seed)
         self.val_rays = DeviceRays(self.val_dataset, self.device, seed + 1)
         self.disp_rays = DeviceRays(self.disp_dataset, self.device, seed + 2)
@@ -153,40 +214,68 @@ class NeRFRunner:
         else:
             self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, list(lr_milestone), lr_gamma, last_epoch=self.last_iter)
 
+    # ----- the two collectives of the logging point (data-parallel runs only; every rank reaches them at the same iterations) -----
+    def _global_loss_and_fault(self, loss, fault: bool):
+        lv = float(loss.detach())
+        if not self.distributed:
+            return lv, fault
+        import torch.distributed as dist
+
+        from . import parallel as par
+
+        total = par.allreduce_host_scalars([lv], dist.ReduceOp.SUM, self.device, self.group)[0]  # the loss is a SUM over rays (nerf.py:328-331)
+        any_fault = par.allreduce_host_scalars([1.0 if fault else 0.0], dist.ReduceOp.MAX, self.device, self.group)[0] > 0.0
+        return total, any_fault  # the same decision on every rank
+
     # nerf.py:445-499
     def trainer(self, mode="train"):
+        from . import parallel as par
+
         rays = {"train": self.train_rays, "val": self.val_rays, "disp": self.disp_rays}[mode]
         it = self.last_iter + 1
         t0, n0 = time.perf_counter(), it
         while it < self.total_iter:
-            for row, col, pix_val, poses_bound, pic in rays.epoch(self.batch_ray):
+            batches = rays.epoch_sharded(self.batch_ray, self.rank, self.world) if self.distributed else rays.epoch(self.batch_ray)
+            for batch in batches:
+                row, col, pix_val, poses_bound, pic = batch[:5]
                 self.optimizer.zero_grad(set_to_none=True)
                 self.model.train()
-                C_coarse, C_fine = self.model(row, col, poses_bound, self.K_inv)
-                loss = self.model.ray_loss(C_coarse, C_fine, pix_val)
-                loss.backward()
+                if self.distributed:
+                    # this rank's slice of the batch: forward + loss + backward into the flat bucket, ONE SUM all-reduce (nerf.py:473-474)
+                    _, _, loss = par.train_step_local(self.model, self.bucket, row, col, poses_bound, self.K_inv, pix_val, batch[5],
+                                                      self.world, self.group)
+                else:
+                    C_coarse, C_fine = self.model(row, col, poses_bound, self.K_inv)
+                    loss = self.model.ray_loss(C_coarse, C_fine, pix_val)
+                    loss.backward()
                 self.optimizer.step()
                 self.scheduler.step()
                 if (it + 1) % self.log_every == 0:  # the only host sync of the loop
-                    lv = float(loss.detach())
+                    # the reference checks its resampling indices in EVERY forward and exit(0)s when a ray's coarse weights have all
+                    # vanished (nerf.py:251-253) -- the state a run that has died stays in.  The kernels keep the bit in a sticky word
+                    # across iterations; it is looked at here, where the loop syncs anyway, so nothing between two logs is missed
+                    fault = self.on_resample_fault != "ignore" and self.model.resample_fault_since(clear=True)
+                    lv, fault = self._global_loss_and_fault(loss, fault)
                     dt = time.perf_counter() - t0
                     self.writer.add_scalar("loss/" + mode, lv, it)
                     self.writer.add_scalar("lr/" + mode, self.optimizer.param_groups[0]["lr"], it)
                     self.writer.flush()
-                    print(f"[ITER] {it} [LOSS] {lv:.4f} [LR] {self.optimizer.param_groups[0]['lr']:.3e} "
-                          f"[{(it + 1 - n0) * self.batch_ray / max(dt, 1e-9):,.0f} rays/s]")
-                    # the reference checks its resampling indices in every forward and exit(0)s when a ray's coarse weights have all
-                    # vanished (nerf.py:251-253) -- the state a run that has died stays in.  Looked at here, where the loop syncs anyway
-                    if self.on_resample_fault != "ignore" and self.model.resample_fault():
+                    if self.rank == 0:
+                        print(f"[ITER] {it} [LOSS] {lv:.4f} [LR] {self.optimizer.param_groups[0]['lr']:.3e} "
+                              f"[{(it + 1 - n0) * self.batch_ray / max(dt, 1e-9):,.0f} rays/s" + (f", {self.world} ranks]" if self.distributed else "]"))
+                    if fault:
                         if self.resample_fault_iter is None:
                             self.resample_fault_iter = it
-                            print(f"[ITER] {it} resample index out of range: the reference prints its banner and exit(0)s here "
-                                  "(nerf.py:251-253); this path clamps the index and trains on (NeRFRunner(on_resample_fault='raise') stops)")
+                            if self.rank == 0:
+                                print(f"[ITER] {it} resample index out of range since the last log: the reference prints its banner and exit(0)s "
+                                      "there (nerf.py:251-253); this path clamps the index" +
+                                      (" and trains on (on_resample_fault='warn')" if self.on_resample_fault == "warn" else ""))
                         if self.on_resample_fault == "raise":
                             from .nerf import ResampleIndexError
 
-                            raise ResampleIndexError(f"iteration {it}: resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253)")
-                if (it + 1) % self.step == 0:
+                            raise ResampleIndexError(f"iteration <= {it}: resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253); "
+                                                     "NeRFRunner(on_resample_fault='warn') trains on")
+                if (it + 1) % self.step == 0 and self.rank == 0:
                     os.makedirs(self.ckpt_path, exist_ok=True)
                     torch.save(self.model, self.ckpt_path + self.start_time + "_" + str(it) + ".pkl")
                 it += 1
@@ -206,13 +295,26 @@ class NeRFRunner:
         # whose ray 0 has the same near / far share kernel calls -- same bits per pixel, launches of up to 16,384 rays instead of 400
         n_keep = rays.num_pix // self.batch_ray * self.batch_ray
         chunk = max(1, (1 << 20) // self.batch_ray) * self.batch_ray  # rays gathered per step (on the batch grid)
-        with torch.no_grad():
-            for s in range(0, n_keep, chunk):
-                row, col, pix_val, poses_bound, pic = rays.gather(torch.arange(s, min(s + chunk, n_keep), device=self.device))
-                _, C_fine = self.model.render(row, col, poses_bound, self.K_inv)
-                result[pic, row, col] = C_fine
+        from . import parallel as par
+
+        prev_batch = self.model.batch_ray
+        self.model.batch_ray = self.batch_ray  # the grid of the reference's display batches (a data-parallel rank's model is built for its slice)
+        try:
+            with torch.no_grad():
+                for s in range(0, n_keep, chunk):
+                    row, col, pix_val, poses_bound, pic = rays.gather(torch.arange(s, min(s + chunk, n_keep), device=self.device))
+                    if self.distributed:
+                        # cfg5: the chunk's reference batches dealt out over the ranks (shards on the batch grid, every call handed its
+                        # batches' ray 0: same pixels for any world size), NO collective in the data path; the picture is assembled after
+                        _, _, C_loc = par.render_rows_sharded(self.model, row, col, poses_bound, self.K_inv, self.rank, self.world)
+                        C_fine = par.gather_rows(C_loc.to(self.device), row.shape[0], self.rank, self.world, self.group, batch=self.batch_ray)
+                    else:
+                        _, C_fine = self.model.render(row, col, poses_bound, self.K_inv)
+                    result[pic, row, col] = C_fine
+        finally:
+            self.model.batch_ray = prev_batch
         result = result.cpu().numpy()
-        if save:
+        if save and self.rank == 0:
             save_dir = self.results_path + self.start_time + "/"
             os.makedirs(save_dir, exist_ok=True)
             try:

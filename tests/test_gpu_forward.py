@@ -447,3 +447,72 @@ def test_render_fuses_batches_bit_identically(oracle, pkg, dev, mode):
             e = min(s + Bm, n)
             _, of = oracle.render(w, row[s:e], col[s:e], pb[s:e], K, 64, 128)
             assert max_rel(Cf[s:e], of) < TOL, s
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_render_one_ray_pieces(oracle, pkg, dev, mode):
+    """a plan can hold a 1-ray piece (n % batch_ray == 1 behind a batch of another near / far; a fuse_rays limit one ray
+    short of the end; an unaligned shard that starts on a batch's last ray).  The library needs B >= 2 (like the reference, nerf.py:208):
+    render() launches such a piece with its ray repeated and crops -- the ray gets the bits the per-batch `forward` gives it."""
+    n, Bm = 1001, 250
+    row, col, pb, K, _ = oracle.lego_inputs(n, seed=31)
+    pb = pb.clone()
+    pb[1000:, 15], pb[1000:, 16] = 2.5, 5.5   # the tail batch (one ray) belongs to another picture
+    w = oracle.make_weights(7, sharp=True)
+    m = pkg.NeRFModel(64, 128, Bm)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    m.bf16_mlp = mode == "bf16"
+    rd, cd, pd = row.to(dev), col.to(dev), pb.to(dev)
+    assert pkg.nerf.fuse_plan(pb[::Bm, 15:17].float().tolist(), n, Bm)[-1] == (1000, 1001, 2.5, 5.5)
+    Cc, Cf = m.render(rd, cd, pd, K)
+    assert Cc.shape == (n, 3) and torch.isfinite(Cf).all()
+    # the last ray as the first ray of a 2-ray batch of its own (ray 0 = itself: its own near / far)
+    m2 = pkg.NeRFModel(64, 128, 2)
+    m2.load_state_dict(w)
+    m2 = m2.to(dev)
+    m2.bf16_mlp = m.bf16_mlp
+    with torch.no_grad():
+        c2, f2 = m2(rd[[1000, 1000]], cd[[1000, 1000]], pd[[1000, 1000]], K)
+    assert torch.equal(Cc[1000], c2[0]) and torch.equal(Cf[1000], f2[0])
+    if mode == "f32":
+        _, of = oracle.render(w, row[[1000, 1000]], col[[1000, 1000]], pb[[1000, 1000]], K, 64, 128)
+        assert max_rel(Cf[1000], of[0]) < TOL
+    # a fuse_rays limit one ray short of the end: same pixels as the unlimited plan
+    pb_same = pb.clone()
+    pb_same[:, 15], pb_same[:, 16] = 2.0, 6.0
+    pds = pb_same.to(dev)
+    full = m.render(rd, cd, pds, K)[1]
+    assert torch.equal(m.render(rd, cd, pds, K, fuse_rays=1000)[1], full)
+    # an unaligned shard that starts on the last ray of batch 1 while batch 2's ray 0 has another near / far
+    pb3 = pb_same.clone()
+    pb3[500:, 15], pb3[500:, 16] = 2.5, 5.5
+    pd3 = pb3.to(dev)
+    full3 = m.render(rd, cd, pd3, K)[1]
+    lo, hi, C = pkg.parallel.render_rows_sharded(m, rd, cd, pd3, K, rank=0, world=1, align_to_batches=False)
+    assert (lo, hi) == (0, n) and torch.equal(C, full3)
+    assert torch.equal(m.render(rd, cd, pd3, K, 499, 900)[1], full3[499:900])
+
+
+def test_sticky_resample_status_survives_later_forwards(oracle, pkg, dev):
+    """nerf_hip_read_status_sticky (ABI 4): the per-forward status word is cleared by the next forward, the sticky one only by the caller
+    -- a loop that looks at its logging points only still learns that some forward in between met nerf.py:251-253's condition."""
+    B = 64
+    row, col, pb, K, _ = oracle.lego_inputs(B, seed=9)
+    w = oracle.make_weights(4, sharp=True)
+    m = pkg.NeRFModel(64, 128, B)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    pb_bad = pb.clone()
+    pb_bad[5, 16] = pb_bad[5, 15]  # ray 5: far = near -> all coarse weights vanish
+    with torch.no_grad():
+        m(row, col, pb, K)
+        assert not m.resample_fault() and not m.resample_fault_since(clear=False)
+        m(row, col, pb_bad, K)
+        assert m.resample_fault() and m.resample_fault_since(clear=False)
+        m(row, col, pb, K)  # a healthy forward clears the per-forward word, not the sticky one
+        assert not m.resample_fault()
+        assert m.resample_fault_since(clear=True)
+        assert not m.resample_fault_since(clear=True)  # cleared by the caller
+        m(row, col, pb, K)
+        assert not m.resample_fault_since()

@@ -47,9 +47,80 @@ def test_bench_train_leg_with_rccl_allreduce():
                                  "strong_train_bf16", "strong_forward_f32_split"}
     for name, leg in out["extra"].items():
         if name.startswith("strong_"):
-            assert leg["value"] > 0 and leg["rays_per_step"] == 4096 and 0.0 < leg["roofline_frac"] < 1.125  # (algorithmic FLOPs: 9/8 of the executed ones)
+            # `roofline.frac` is a HARDWARE fraction (executed FLOPs or measured bytes over the peak): never above 1
+            assert leg["value"] > 0 and leg["rays_per_step"] == 4096 and 0.0 < leg["roofline_frac"] <= 1.0
         else:
-            assert leg["value"] > 0 and 0.0 < leg["roofline"]["frac"] < 1.125 and leg["roofline"].get("frac_executed", 0.0) < 1.0
+            assert leg["value"] > 0 and 0.0 < leg["roofline"]["frac"] <= 1.0
+            if "frac_algorithmic" in leg["roofline"]:  # the reference graph's FLOPs over the same time: 9/8 of the executed ones (the fold)
+                assert leg["roofline"]["frac"] < leg["roofline"]["frac_algorithmic"] < 1.125
+    assert 0.0 < out["roofline"]["frac"] <= 1.0
+    for ph in out["roofline_phases"].values():
+        assert 0.0 < ph["frac"] <= 1.0
     assert out["extra"]["train_bf16"]["allreduce_ms"] is not None
     assert out["extra"]["strong_train_f32"]["allreduce_ms"] is not None and out["extra"]["strong_train_bf16"]["allreduce_ms"] is not None
     assert out["parity"]["pass"] is True and out["parity"]["split_mlp_vs_reference"]["pass"] is True
+
+
+def _run_ranks(n, out, extra=(), backend=None, timeout=500):
+    """n ranks of tests/tools/dp_runner_rank.py under torch.distributed.run (n = 0: the plain single-process runner), fresh processes."""
+    import socket
+
+    tool = os.path.join(ROOT, "tests", "tools", "dp_runner_rank.py")
+    env = _env()
+    if backend:
+        env["NERF_DIST_BACKEND"] = backend
+    if n == 0:
+        cmd = [sys.executable, tool, out, *extra]
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), tool, out, *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "DP-RUNNER-OK" in r.stdout
+    import torch
+
+    return torch.load(os.path.join(out, "result.pt"), weights_only=False)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("bf16", [False, True])
+def test_data_parallel_runner_single_rank_rccl_equals_plain_runner(tmp_path, bf16):
+    """NeRFRunner under a launcher.  One rank over a REAL RCCL group (the collective is the identity): the data-
+    parallel loop -- sharded sampler, gradients in the flat bucket, overlapped all-reduce, fused Adam on the views, rank 0 logging and
+    checkpointing, display() through render_rows_sharded + gather_rows -- must leave bit-identical weights, losses and frames to the
+    plain single-process runner (same kernels, same order of the same batches)."""
+    import torch
+
+    extra = ("--bf16",) if bf16 else ()
+    plain = _run_ranks(0, str(tmp_path / "plain"), extra)
+    dp = _run_ranks(1, str(tmp_path / "dp1"), extra + ("--force-dist",))
+    assert plain["distributed"] is False and dp["distributed"] is True and dp["ranks"] == 1 and dp["local_rays"] == 256
+    assert plain["losses"] == dp["losses"] and len(dp["losses"]) == 6
+    assert torch.equal(plain["weights"], dp["weights"])
+    assert torch.equal(plain["frame"], dp["frame"])
+    assert len(dp["ckpts"]) == 2 and dp["ckpts"][-1].endswith("_5.pkl") and dp["images"] == 3
+
+
+@pytest.mark.timeout(900)
+def test_data_parallel_runner_two_ranks_follow_the_single_process_run(tmp_path):
+    """Two ranks on the box's one GPU (process group over gloo: RCCL refuses two ranks on one device; same runner code): each trains on
+    its half of every 256-ray batch, the halves' gradients are SUM-all-reduced, both take the same Adam step.  The job's loss curve (the
+    SUM of the ranks' losses) follows the single-process run on the same batches to summation order, the weights stay replicated (checked
+    inside the ranks), the frame rendered tile-sharded over the two ranks is bit-identical to the single-process render of the same weights
+    -- compared here through weights that differ only by summation order: 1e-3."""
+    import torch
+
+    plain = _run_ranks(0, str(tmp_path / "plain"))
+    dp = _run_ranks(2, str(tmp_path / "dp2"), backend="gloo")
+    assert dp["ranks"] == 2 and dp["local_rays"] == 128 and len(dp["ckpts"]) == 2 and dp["images"] == 3
+    for a, b in zip(plain["losses"], dp["losses"]):
+        assert abs(a - b) <= 2e-4 * abs(a), (plain["losses"], dp["losses"])
+    # Adam's first steps are sign-like (|update| ~ lr per element whatever the gradient's size), so elements whose gradient is at rounding
+    # level may differ by up to 2 lr per step; the bulk must agree closely
+    d = (plain["weights"] - dp["weights"]).abs()
+    assert float(d.max()) <= 2 * 1e-3 * 6 and float((d > 1e-5).float().mean()) < 0.02
+    assert float((plain["frame"] - dp["frame"]).abs().max()) < 5e-3

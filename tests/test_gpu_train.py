@@ -284,8 +284,8 @@ def test_training_trajectory_follows_the_oracle_with_torch_adam(oracle, pkg, dev
 def test_runner_reports_the_references_exit_condition(pkg, dev, tmp_path):
     """nerf.py:251-253: the reference prints a banner and exit(0)s when a ray's resampling index leaves [0, Nf-1] -- all coarse weights of
     the ray vanished, the state a training run that has died stays in (tests/tools/collapse_stats.py: the reference's own recipe reaches it
-    in a third of the runs at its default learning rate).  The device path clamps and trains on; the runner looks at the status word where
-    it syncs anyway and warns (default), raises, or ignores."""
+    in a third of the runs at its default learning rate).  The device path clamps and trains on; the runner looks at the STICKY status word where
+    it syncs anyway and raises (default, like the reference stops), warns, or ignores."""
     scene = pkg.data.synthetic_scene(n_pic=2, H=16, W=16, seed=3)
     kw = dict(gpu=0, img_dir="", results_path=str(tmp_path) + "/r/", ckpt_path=str(tmp_path) + "/c/", low_res=1, total_iter=4, batch_ray=128,
               learning=1e-5, n_coarse=16, n_fine=32, step=10 ** 9, decay_end=10000, sched="EXP", datasets={"train": scene, "val": scene, "test": scene},
@@ -299,13 +299,72 @@ def test_runner_reports_the_references_exit_condition(pkg, dev, tmp_path):
     run = pkg.NeRFRunner(**kw)
     run.trainer("train")
     assert run.resample_fault_iter is None and not run.model.resample_fault()  # a healthy run says nothing
-    run = pkg.NeRFRunner(**kw)
+    run = pkg.NeRFRunner(on_resample_fault="warn", **kw)
     dead(run)
     assert run.trainer("train") == 3 and run.resample_fault_iter == 1  # warned at the first logged iteration, trained on
-    run = pkg.NeRFRunner(on_resample_fault="raise", **kw)
+    run = pkg.NeRFRunner(**kw)  # the default mirrors the reference: stop
+    assert run.on_resample_fault == "raise"
     dead(run)
     with pytest.raises(pkg.nerf.ResampleIndexError):
         run.trainer("train")
+    # a fault BETWEEN two logging points is not missed: dead for iteration 0 only, healthy again at the logged iteration 1
+    run = pkg.NeRFRunner(on_resample_fault="warn", **kw)
+    healthy = [p.detach().clone() for p in run.model.network.sigma_layer.parameters()]
+    dead(run)
+    calls = {"n": 0}
+    real_step = run.optimizer.step
+
+    def step_and_revive():
+        calls["n"] += 1
+        if calls["n"] == 1:  # no update from the dead iteration; the network is healthy again from iteration 1 on
+            with torch.no_grad():
+                for p, h in zip(run.model.network.sigma_layer.parameters(), healthy):
+                    p.copy_(h)
+        else:
+            real_step()
+
+    run.optimizer.step = step_and_revive
+    assert run.trainer("train") == 3
+    assert run.resample_fault_iter == 1 and not run.model.resample_fault()  # seen at the log although that iteration's own forward was healthy
     run = pkg.NeRFRunner(on_resample_fault="ignore", **kw)
     dead(run)
     assert run.trainer("train") == 3 and run.resample_fault_iter is None
+
+
+def test_plain_loop_in_bucket_mode_needs_no_consume_call(oracle, pkg, dev):
+    """``model.grad_bucket = bucket; loss.backward(); opt.step()`` in a plain single-process loop.  FusedAdam.step (and
+    .zero_grad) release the bucket whose views are the gradients it used, so the second backward does not raise; the weights after k steps
+    are bit-identical to the loop without a bucket (same kernels, the gradients only live in another buffer); a second backward WITHOUT a
+    step in between still raises (it would overwrite unused gradients)."""
+    Bs = 96
+    row, col, pb, K, C_true = oracle.lego_inputs(Bs, seed=11)
+    w = oracle.make_weights(3, sharp=True)
+    ms = []
+    for use_bucket in (False, True):
+        m = pkg.NeRFModel(64, 128, Bs)
+        m.load_state_dict(w)
+        m = m.to(dev)
+        opt = pkg.FusedAdam([{"params": list(m.network.parameters()), "initial_lr": 1e-3}], lr=1e-3, betas=(0.9, 0.999), eps=1e-7)
+        if use_bucket:
+            m.grad_bucket = pkg.parallel.GradBucket(m.network.parameters())
+        for it in range(4):
+            if it % 2 == 0:
+                opt.zero_grad(set_to_none=True)   # the runner's form; every other step relies on FusedAdam.step's release alone
+            Cc, Cf = m(row, col, pb, K)
+            m.ray_loss(Cc, Cf, C_true.to(dev)).backward()
+            if use_bucket:
+                assert m.grad_bucket.pending and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(m.network.parameters(), m.grad_bucket.views))
+            opt.step()
+            if use_bucket:
+                assert not m.grad_bucket.pending
+        ms.append(m)
+    for p, q in zip(ms[0].network.parameters(), ms[1].network.parameters()):
+        assert torch.equal(p, q)
+    m = ms[1]
+    Cc, Cf = m(row, col, pb, K)
+    loss = m.ray_loss(Cc, Cf, C_true.to(dev))
+    loss.backward(retain_graph=False)
+    Cc, Cf = m(row, col, pb, K)
+    with pytest.raises(RuntimeError, match="second backward"):
+        m.ray_loss(Cc, Cf, C_true.to(dev)).backward()
+    m.grad_bucket.consume()

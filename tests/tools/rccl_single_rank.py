@@ -101,6 +101,34 @@ def main():
         assert same(b_ov.flat, want), f"overlapped all-reduce changed the gradients (bf16={bf})"
         assert not b_ov.pending
 
+    # (d3) ORDERING of the overlap: with one rank the all-reduce is the identity, so an event recorded too early would
+    # still leave the right final buffer.  Check the event itself: poison the buffer, run forward + backward by hand with the bucket's
+    # event, and on the side stream BEHIND the event copy the early part away while the compute stream is still busy with the remaining
+    # products.  The copy must already be the final early part, bit for bit (a product of point_layer[0..7] moved behind the event, or a
+    # reduce that was split differently, would leave poison or partial sums in it).
+    for bf in (False, True):
+        m4 = model(B)
+        m4.bf16_mlp = bf
+        b4 = par.GradBucket(m4.network.parameters()).enable_overlap()
+        for rep in range(2):
+            b4.flat.fill_(float("nan"))
+            torch.cuda.synchronize()
+            m4.grad_bucket = b4
+            Cc, Cf = m4(row, col, pbd, K)
+            m4.ray_loss(Cc, Cf, Ctd).backward()   # nerf_hip_backward_overlap records b4.early_event where tensors 0..15 are final
+            snap = torch.empty(b4.early_numel, device=dev)
+            b4.side_stream.wait_event(b4.early_event)
+            with torch.cuda.stream(b4.side_stream):
+                snap.copy_(b4.flat[: b4.early_numel], non_blocking=True)
+            torch.cuda.synchronize()
+            m4.grad_bucket = None
+            b4.consume()
+            early_real = torch.cat([v.reshape(-1) for v in b4.views[:16]])
+            assert torch.isfinite(early_real).all(), f"early part not written (bf16={bf})"
+            assert torch.equal(torch.nan_to_num(snap, nan=-7.0), torch.nan_to_num(b4.flat[: b4.early_numel], nan=-7.0)), \
+                f"the early event fired before point_layer[0..7]'s gradients were final (bf16={bf}, rep={rep})"
+            assert torch.isfinite(torch.cat([v.reshape(-1) for v in b4.views[16:]])).all()
+
     # (e) the fused optimizer steps from the bucket views
     opt = P.FusedAdam(list(m1.network.parameters()), lr=1e-3)
     before = m1.network.point_info.weight.detach().clone()
@@ -109,7 +137,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
-    print("RCCL-OK single-rank nccl group: bucketed backward, all-reduce, overlapped all-reduce, shard sum, bf16, fused Adam")
+    print("RCCL-OK single-rank nccl group: bucketed backward, all-reduce, overlapped all-reduce + event ordering, shard sum, bf16, fused Adam")
 
 
 if __name__ == "__main__":
