@@ -171,7 +171,7 @@ def _bf16(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def mlp_bf16(params, gp: torch.Tensor, gd: torch.Tensor, return_hidden: bool = False):
+def mlp_bf16(params, gp: torch.Tensor, gd: torch.Tensor, return_hidden: bool = False, _round_act=None):
     """NOT a restatement of the reference (which has no reduced precision): the arithmetic the build's bf16-MLP variant
     (BASELINE.json cfg3, flag NERF_HIP_BF16_MLP) is specified to perform, emulated in fp32 -- same graph as ``mlp``
     (nerf.py:101-124) with every linear layer's weights AND inputs rounded to bf16 (RNE), fp32 products/accumulation,
@@ -182,12 +182,13 @@ def mlp_bf16(params, gp: torch.Tensor, gd: torch.Tensor, return_hidden: bool = F
     Used only to check that variant (tests/test_gpu_bf16.py)."""
     W = lambda n: _bf16(params[n])
     b = lambda n: params[n]
-    gp, gd = _bf16(gp), _bf16(gd)
+    ra = _round_act or _bf16  # rounding of the ACTIVATIONS (encodings, layer outputs); mlp_bf16_jittered perturbs them before it
+    gp, gd = ra(gp), ra(gd)
     h = gp
     hidden = []
     for i in range(8):
         inp = torch.cat((h, gp), dim=-1) if i == 4 else h
-        h = _bf16(torch.relu(F.linear(inp, W(f"network.point_layer.{i}.0.weight"), b(f"network.point_layer.{i}.0.bias"))))
+        h = ra(torch.relu(F.linear(inp, W(f"network.point_layer.{i}.0.weight"), b(f"network.point_layer.{i}.0.bias"))))
         hidden.append(h)
     sigma = torch.abs(F.linear(h, W("network.sigma_layer.0.weight"), b("network.sigma_layer.0.bias")))
     Wd, Wp = params["network.dir_info.0.weight"], params["network.point_info.weight"]
@@ -195,11 +196,28 @@ def mlp_bf16(params, gp: torch.Tensor, gd: torch.Tensor, return_hidden: bool = F
     W_fold = _bf16(Wd[:, n_d:] @ Wp)
     b_fold = Wd[:, n_d:] @ b("network.point_info.bias") + b("network.dir_info.0.bias")
     feat = F.linear(h, W("network.point_info.weight"), b("network.point_info.bias"))  # (not part of the folded graph; returned for inspection)
-    c = _bf16(torch.relu(F.linear(gd, _bf16(Wd[:, :n_d])) + F.linear(h, W_fold) + b_fold))
+    c = ra(torch.relu(F.linear(gd, _bf16(Wd[:, :n_d])) + F.linear(h, W_fold) + b_fold))
     rgb = torch.sigmoid(F.linear(c, W("network.color_layer.0.weight"), b("network.color_layer.0.bias")))
     if return_hidden:
         return rgb, sigma.squeeze(-1), hidden, feat, c
     return rgb, sigma.squeeze(-1)
+
+
+def mlp_bf16_jittered(seed: int, rel: float = 1e-6):
+    """``mlp_bf16`` as ANOTHER correct evaluation of the same specification would compute it: every fp32 value that is about to be
+    rounded to bf16 (the encodings, every layer's activated output) is first moved by a seeded relative `rel` -- the size of fp32
+    summation-order and 1-ulp sin / cos differences (1.3e-6) -- so that now and then a bf16 rounding flips, which
+    is exactly how the device kernels differ from the emulation.  Used to compute the emulation's OWN sensitivity
+    band for the gradient and trajectory tests of the bf16 variant (tests/test_gpu_bf16.py); deterministic per (seed, call order)."""
+    gen = torch.Generator().manual_seed(seed)
+
+    def round_act(x):
+        return _bf16(x * (1.0 + rel * torch.randn(x.shape, generator=gen)))
+
+    def f(params, gp, gd, return_hidden=False):
+        return mlp_bf16(params, gp, gd, return_hidden, _round_act=round_act)
+
+    return f
 
 
 def weights_from_sigma(delta: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:

@@ -169,12 +169,30 @@ def test_bf16_full_loss_gradients(oracle, pkg, dev, name):
     eloss = oracle.ray_loss(Ec, Ef, Ct)
     eloss.backward()
     assert abs(float(loss.detach()) - float(eloss.detach())) < 2e-2 * abs(float(eloss.detach()))
-    worst = 0.0
-    for (k, pe), pm in zip(p.items(), m.network.parameters()):
-        ge, gm = pe.grad.double().flatten(), pm.grad.double().flatten().cpu()
+    # The bar, per tensor (as tests/test_gpu_backward.py::test_train_step_end_to_end does for fp32, here THROUGH the bf16 emulation): twice
+    # the emulation's OWN gradient shift when every value it rounds to bf16 is first moved by a seeded relative 1e-6 (oracle.
+    # mlp_bf16_jittered: another correct evaluation of the same specification -- a few flipped bf16 roundings, which then flip sort
+    # ties and ReLU kinks on the t_fine path), maximum over two seeds; floor 3e-2 = the bar of the well-conditioned coarse-only gradients
+    # above (the kernels additionally round every gradient that enters an MFMA to bf16).
+    g0 = {k: pe.grad.detach().double().flatten() for k, pe in p.items()}
+    band = {k: 0.0 for k in g0}
+    for sd in (1, 2):
+        pj = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        Jc, Jf = oracle.render(pj, row, col, pb, K, Nc, Nf, mlp=oracle.mlp_bf16_jittered(sd), check=False)
+        oracle.ray_loss(Jc, Jf, Ct).backward()
+        for k in band:
+            band[k] = max(band[k], float((pj[k].grad.double().flatten() - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)))
+    worst = (0.0, 1.0, "")
+    for (k, ge), pm in zip(g0.items(), m.network.parameters()):
+        gm = pm.grad.double().flatten().cpu()
         assert torch.isfinite(gm).all(), k
-        worst = max(worst, float((gm - ge).norm() / ge.norm().clamp_min(1e-30)))
-    assert worst < 0.5, worst
+        e = float((gm - ge).norm() / ge.norm().clamp_min(1e-30))
+        bar = max(2.0 * band[k], 3e-2)
+        if e / bar > worst[0] / worst[1]:
+            worst = (e, bar, k)
+        assert e < bar, (k, e, band[k])
+    print(f"{name}: bf16 full-loss gradient closest to its bar: {worst[2]} L2-rel {worst[0]:.2e} (bar {worst[1]:.2e}; the emulation's own "
+          f"1e-6 jitter bands span {min(band.values()):.1e} .. {max(band.values()):.1e})")
 
 
 @pytest.mark.parametrize("B,Nc,Nf", [(7, 5, 3), (33, 100, 200), (3, 1024, 1024), (130, 31, 65)])
@@ -251,3 +269,102 @@ def test_bf16_training_learns(pkg, dev):
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+
+
+def test_bf16_training_trajectory_follows_the_emulation(oracle, pkg, dev):
+    """SURVEY.md section 7 hard-6's acceptance for cfg3 -- "<= 2e-2 max-rel, and loss-curve agreement" -- as the bf16 twin of
+    tests/test_gpu_train.py::test_training_trajectory_follows_the_oracle_with_torch_adam: 30 iterations of the reference's trainer loop
+    (nerf.py:468-475; Adam betas (0.9, 0.999), eps 1e-7, the EXP schedule of nerf.py:425-426 with both branches walked), the bf16
+    EMULATION (oracle.mlp_bf16 through the oracle's renderer, autograd) + torch.optim.Adam on the CPU against NeRFModel(bf16_mlp) +
+    FusedAdam on the GPU, same ray batches and start weights.
+    (a) Teacher-forced: at every step the device evaluates the loss at the EMULATION's current weights: within the bf16 forward bar
+        (1e-2 relative: C_fine's bar in test_forward_bf16) along the whole trajectory.
+    (b) Free-running: inside a band computed from the emulation's OWN drift -- its run with every to-be-rounded value jittered by a seeded
+        relative 1e-6 (oracle.mlp_bf16_jittered) against its unjittered run: three times the maximum over two seeds per step (floor: the
+        forward bar), for the loss curve and for the final weights.
+    (c) The fp32-vs-bf16 gap of the loss curve is asserted: the bf16 device run ends within 10 % of the fp32 device run's final loss on
+        the same batches and both learn -- reduced precision in the MLP does not change what the trainer converges towards."""
+    B, Nc, Nf, steps, lr0, gamma, decay_end = 64, 16, 32, 30, 3e-4, 0.1, 20
+    FWD_BAR = 1e-2
+    lam = lambda it: gamma ** (it / decay_end) if it < decay_end else gamma * lr0  # nerf.py:426
+    batches = [oracle.lego_inputs(B, seed=100 + s) for s in range(steps)]
+    w0 = oracle.make_weights(3, sharp=False)
+
+    def cpu_run(mlp_of_step, keep=False):
+        params = {k: v.clone().requires_grad_(True) for k, v in w0.items()}
+        opt = torch.optim.Adam([{"params": list(params.values()), "initial_lr": lr0}], lr=lr0, betas=(0.9, 0.999), eps=1e-7)
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lam)
+        losses, snaps = [], []
+        for s, (row, col, pb, K, Ct) in enumerate(batches):
+            if keep:
+                snaps.append({k: v.detach().clone() for k, v in params.items()})
+            opt.zero_grad(set_to_none=True)
+            Ec, Ef = oracle.render(params, row, col, pb, K, Nc, Nf, mlp=mlp_of_step(s), check=False)
+            loss = oracle.ray_loss(Ec, Ef, Ct)
+            loss.backward()
+            opt.step()
+            sch.step()
+            losses.append(float(loss.detach()))
+        return losses, {k: v.detach().clone() for k, v in params.items()}, snaps
+
+    ref_l, ref_w, snaps = cpu_run(lambda s: oracle.mlp_bf16, keep=True)
+    band_l, band_w = [0.0] * steps, {k: 0.0 for k in w0}
+    for sd in (1, 2):
+        pl, pw, _ = cpu_run(lambda s: oracle.mlp_bf16_jittered(1000 * sd + s))
+        band_l = [max(b, abs(a - r)) for b, a, r in zip(band_l, pl, ref_l)]
+        for k in band_w:
+            band_w[k] = max(band_w[k], float((pw[k] - ref_w[k]).norm() / ref_w[k].norm()))
+
+    def device_model(w, bf16):
+        m = pkg.NeRFModel(Nc, Nf, B)
+        m.load_state_dict(w)
+        m = m.to(dev)
+        m.bf16_mlp = bf16
+        return m
+
+    # (a) teacher-forced
+    tf = device_model(w0, True)
+    worst_tf = 0.0
+    with torch.no_grad():
+        for s, (row, col, pb, K, Ct) in enumerate(batches):
+            tf.load_state_dict(snaps[s])
+            tf.force_tile_kernel = True  # the 32x32x16 form, i.e. the forward half of a training call
+            Cc, Cf = tf(row, col, pb, K)
+            e = abs(float(tf.ray_loss(Cc, Cf, Ct.to(dev))) - ref_l[s]) / ref_l[s]
+            worst_tf = max(worst_tf, e)
+            assert e <= FWD_BAR, (s, e)
+
+    # (b) free-running, bf16; (c) the fp32 device run on the same batches
+    def device_run(bf16):
+        m = device_model(w0, bf16)
+        opt = pkg.FusedAdam([{"params": list(m.network.parameters()), "initial_lr": lr0}], lr=lr0, betas=(0.9, 0.999), eps=1e-7)
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lam)
+        out = []
+        m.train()
+        for row, col, pb, K, Ct in batches:
+            opt.zero_grad(set_to_none=True)
+            Cc, Cf = m(row, col, pb, K)
+            loss = m.ray_loss(Cc, Cf, Ct.to(dev))
+            loss.backward()
+            opt.step()
+            sch.step()
+            out.append(float(loss.detach()))
+        return out, m
+
+    dev_l, m = device_run(True)
+    worst = 0.0
+    for s, (a, r, b) in enumerate(zip(dev_l, ref_l, band_l)):
+        bar = max(3.0 * b, FWD_BAR * abs(r))
+        worst = max(worst, abs(a - r) / bar)
+        assert abs(a - r) <= bar, (s, a, r, b)
+    for (k, v), q in zip(ref_w.items(), m.network.parameters()):
+        e = float((q.detach().cpu() - v).norm() / v.norm())
+        assert e <= max(3.0 * band_w[k], 1e-3), (k, e, band_w[k])
+    f32_l, _ = device_run(False)
+    gap = abs(dev_l[-1] - f32_l[-1]) / f32_l[-1]
+    curve_gap = max(abs(a - b) / b for a, b in zip(dev_l, f32_l))
+    assert dev_l[-1] < 0.6 * dev_l[0] and ref_l[-1] < 0.6 * ref_l[0] and f32_l[-1] < 0.6 * f32_l[0]  # all three trainers learn
+    assert gap < 0.10 and curve_gap < 0.15, (gap, curve_gap)
+    print(f"bf16 trajectory: {steps} steps, loss {ref_l[0]:.3f} -> {ref_l[-1]:.3f} (emulation) / {dev_l[-1]:.3f} (device bf16) / {f32_l[-1]:.3f} (device fp32); "
+          f"teacher-forced worst rel {worst_tf:.1e} (bar {FWD_BAR:.0e}); free-running largest |dev - emulation| / bar = {worst:.2f}; the emulation's own "
+          f"jitter drift at the last step {band_l[-1] / ref_l[-1]:.1e} rel; fp32-vs-bf16 final-loss gap {gap:.1e}, largest along the curve {curve_gap:.1e}")
