@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -53,6 +54,15 @@ int check_sizes(int B, int Nc, int Nf) {
 
 // wave blocks (32 samples) of one pass of the bf16 kernels: whole 256-sample workgroups
 size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
+
+// bf16 weight-gradient phase: all products in one or two launches (dw_bf16.hip: k_dw_bf16_multi) up to this many wave blocks -- where the
+// per-product launches' slabs (219 MB per step whatever the batch) and launch boundaries weigh -- and a launch per product beyond.
+// NERF_DW_BF16_MULTI=0 / 1 overrides the choice (A/B measurements only).
+constexpr int DW_BF16_MULTI_MAX_WB = 8192;  // 1,365 rays x (64 + 128)
+bool dw_bf16_multi(int wb_tot) {
+  static const int forced = [] { const char* e = getenv("NERF_DW_BF16_MULTI"); return e ? atoi(e) : -1; }();
+  return forced >= 0 ? forced != 0 : wb_tot <= DW_BF16_MULTI_MAX_WB;
+}
 
 
 // The eleven weight-gradient products of the fp32 train step (dw_f32.hip) -- ten MFMA-bound ones, one of them carrying the sigma
@@ -501,6 +511,54 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
       r.slabs = sl; r.nslab = nslab; r.rows = rows; r.ni = ni; r.o_first = o_first; r.o_count = o_count; r.i_first = i_first; r.i_count = i_count;
       r.dW = dW; r.ldw = ldw; r.col0 = col0; r.db = db;
     };
+    if (dw_bf16_multi(wb_tot)) {
+      // SMALL batch (a rank's share of a strong-scaling step, the reference's 400-ray batch): all products of the early part in ONE
+      // launch and all of the late part in another (ONE launch for everything without an early event), the workgroups dealt out in
+      // proportion to the products' bytes: a quarter of the slab traffic, three or four launch boundaries fewer, long streams
+      static const int layers[6] = {1, 2, 3, 5, 6, 7};
+      DwBfProd pr[10];
+      memset(pr, 0, sizeof(pr));
+      int n = 0;
+      pr[n++] = DwBfProd{Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, nullptr, 0};                                   // 0: layer 0 (X = gamma_p)
+      for (int k = 0; k < 6; ++k) pr[n++] = DwBfProd{Gt(BG_L0 + layers[k]), 16, X(BS_H0 + layers[k] - 1), 16, nullptr, 0, nullptr, nullptr, 0};  // 1..6
+      pr[n++] = DwBfProd{Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, nullptr, 0};                        // 7: layer 4, X = [h3 | gamma_p]
+      const int n_early = n;
+      pr[n++] = DwBfProd{Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), nullptr, 0};                              // 8: folded dir_info product + sigma head
+      pr[n++] = DwBfProd{Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, nullptr, 0};                                       // 9: colour head
+      auto early_reds = [&]() {
+        red(pr[0].slabs, pr[0].nslab, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1]);
+        for (int k = 0; k < 6; ++k) red(pr[1 + k].slabs, pr[1 + k].nslab, 256, 256, 0, 256, 0, WIDTH, dw[2 * layers[k]], WIDTH, 0, dw[2 * layers[k] + 1]);
+        red(pr[7].slabs, pr[7].nslab, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
+      };
+      auto late_reds = [&]() {
+        red(pr[8].slabs, pr[8].nslab, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR]);
+        red(pr[8].slabs, pr[8].nslab, 160, 288, 0, HALF, 32, WIDTH, at<float>(ws, L.mbuf), WIDTH, 0, nullptr);
+        red(pr[8].slabs, pr[8].nslab, 160, 288, HALF + 3, 1, 32, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr);
+        red(pr[9].slabs, pr[9].nslab, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR]);
+        red(pr[9].slabs, pr[9].nslab, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA]);
+      };
+      float* end = slabs;
+      if (early_event) {
+        HIP_TRY(launch_dw_bf16_multi(pr, n_early, wb_tot, slabs, &end, st));
+        early_reds();
+        HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
+        HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(early_event), st));
+        rb.n = 0;
+        HIP_TRY(launch_dw_bf16_multi(pr + n_early, n - n_early, wb_tot, end, &end, st));
+        late_reds();
+      } else {
+        HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, &end, st));
+        early_reds();
+        late_reds();
+      }
+      if ((size_t)(end - at<float>(ws, L.bslabs)) > dw_bf16_slab_floats()) return fail(NERF_HIP_ERR_WORKSPACE, "bf16 slab space exceeded");
+      HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
+      FoldGradArgs fg;
+      fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
+      fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
+      HIP_TRY(launch_fold_grads(fg, st));
+      return NERF_HIP_OK;
+    }
     // layer 0: X = gamma_p
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
     red(slabs, ns, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1]);

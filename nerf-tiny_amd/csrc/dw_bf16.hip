@@ -72,15 +72,15 @@ struct DwbGeom {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+// The body of one workgroup: product `gi` of the argument block, workgroup `wg` of the `nwg` that share that product's samples; its
+// partial sums go to slab_base + wg * rows * ld.
 template <int NIT, bool HAS_Z>
-__global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+__device__ __forceinline__ void dw_bf16_body(const DwBfArgs& a, unsigned char* lds, const int gi, const int wg, const int nwg, float* slab_base) {
   using Geo = DwbGeom<NIT, HAS_Z>;
   constexpr int XKS = Geo::XKS, NSLOT = Geo::NSLOT, NPW = Geo::NPW;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
-  const int gi = blockIdx.x % a.ngemm, wg = blockIdx.x / a.ngemm, nwg = gridDim.x / a.ngemm;
   const unsigned char* const gG = a.G[gi];
   const unsigned char* const gX1 = a.X1[gi];
   const int per = (a.wb_tot + nwg - 1) / nwg;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
   // accumulator layout: lane l holds column l & 31 and rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)
   const int NI = NIT * 32, ld = NI + 1;
   const int rows = a.o_tiles * 32 + (HAS_Z ? 32 : 0);
-  float* slab = a.slabs + (size_t)(gi * nwg + wg) * rows * ld;
+  float* slab = slab_base + (size_t)wg * rows * ld;
   const int n = lane & 31, hh = lane >> 5;
   if (worker) {
 #pragma unroll
@@ -171,6 +171,46 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
       const int i = 32 * zt + (r & 3) + 8 * (r >> 2) + 4 * hh;
       slab[(size_t)(a.o_tiles * 32 + n) * ld + i] = accz[r];
     }
+  }
+}
+
+template <int NIT, bool HAS_Z>
+__global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int gi = blockIdx.x % a.ngemm, wg = blockIdx.x / a.ngemm, nwg = gridDim.x / a.ngemm;
+  const int rows = a.o_tiles * 32 + (HAS_Z ? 32 : 0);
+  dw_bf16_body<NIT, HAS_Z>(a, lds, gi, wg, nwg, a.slabs + (size_t)gi * nwg * rows * (NIT * 32 + 1));
+}
+
+// ---- SMALL batches: every product of the step (or of its early / late part) in ONE launch -------------------------------------------
+// A launch per product hands each of them ALL workgroups and so a slab per workgroup: 219 MB of partial sums written and read back per
+// step whatever the batch -- a third of the phase at 512 rays (0.31 ms against 0.17 for an eighth of the 4096-ray phase) -- behind five
+// launch boundaries and with 12-block streams whose ring never fills.  Here the workgroups of ONE launch are dealt out over the
+// products in proportion to their bytes per wave block: as many CUs busy, streams of 100+ blocks, a quarter of the slabs.  Products of
+// different shapes run different instantiations of the same body behind a block-uniform switch.
+struct DwBfMulti {
+  static constexpr int MAXP = 12;
+  DwBfArgs a[MAXP];     // per product (ngemm = 1, product index 0); a[i].slabs = its slab base
+  int kind[MAXP];       // instantiation: 2 * NIT + HAS_Z
+  int wg0[MAXP + 1];    // first workgroup of product i (wg0[n] = grid size)
+  int n;
+};
+
+__global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16_multi(const DwBfMulti m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int i = 0;
+#pragma unroll 1
+  while (i + 1 < m.n && (int)blockIdx.x >= m.wg0[i + 1]) ++i;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const DwBfArgs& a = m.a[i];
+  const int wg = blockIdx.x - m.wg0[i], nwg = m.wg0[i + 1] - m.wg0[i];
+  switch (m.kind[i]) {
+    case 2 * 10 + 0: dw_bf16_body<10, false>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 9 + 1: dw_bf16_body<9, true>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 8 + 0: dw_bf16_body<8, false>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 4 + 0: dw_bf16_body<4, false>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 2 + 0: dw_bf16_body<2, false>(a, lds, 0, wg, nwg, a.slabs); break;
+    default: break;
   }
 }
 
@@ -308,6 +348,73 @@ hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned c
   if (nwg > wb_tot) nwg = wb_tot;
   *nslab = nwg;
   return dwb_launch<8, false>(a, nwg * n, st);
+}
+
+// n (<= 12) products of ANY of the shapes above in ONE launch of (at most) DWB_WGS workgroups, dealt out in proportion to the bytes a
+// product reads per wave block (largest remainder, at least one each, never more than wave blocks).  Fills p[i].slabs / p[i].nslab
+// (carved from slab_base in order) and returns the end of the used slab space in *slab_end.
+hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, float** slab_end, hipStream_t st) {
+  if (n < 1 || n > DwBfMulti::MAXP || wb_tot < 1) return hipErrorInvalidValue;
+  DwBfMulti m;
+  memset(&m, 0, sizeof(m));
+  m.n = n;
+  int pieces[DwBfMulti::MAXP], total = 0;
+  for (int i = 0; i < n; ++i) { pieces[i] = p[i].g_ks + p[i].x1_ks + p[i].x2_ks + (p[i].Z ? 2 : 0); total += pieces[i]; }
+  const int budget = DWB_WGS;
+  int nwg[DwBfMulti::MAXP], used = 0;
+  for (int i = 0; i < n; ++i) {
+    nwg[i] = (int)((long long)budget * pieces[i] / total);
+    if (nwg[i] < 1) nwg[i] = 1;
+    if (nwg[i] > wb_tot) nwg[i] = wb_tot;
+    used += nwg[i];
+  }
+  // hand the remaining workgroups to the products with the most bytes per workgroup (fixed order: deterministic slabs)
+  while (used < budget) {
+    int best = -1;
+    double worst = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double load = (double)pieces[i] / nwg[i];
+      if (nwg[i] < wb_tot && load > worst) { worst = load; best = i; }
+    }
+    if (best < 0) break;
+    ++nwg[best]; ++used;
+  }
+  while (used > budget) {  // (only when n > budget or the minimum of one each overshoots: not with 12 products)
+    int best = -1;
+    double least = 1e30;
+    for (int i = 0; i < n; ++i) {
+      const double load = (double)pieces[i] / nwg[i];
+      if (nwg[i] > 1 && load < least) { least = load; best = i; }
+    }
+    if (best < 0) break;
+    --nwg[best]; --used;
+  }
+  float* slab = slab_base;
+  int wg0 = 0;
+  for (int i = 0; i < n; ++i) {
+    DwBfArgs& a = m.a[i];
+    const int xks = p[i].x1_ks + p[i].x2_ks, nit = xks / 2;
+    const bool z = p[i].Z != nullptr;
+    if (xks % 2 || !((nit == 10 && !z) || (nit == 9 && z) || (nit == 8 && !z) || (nit == 4 && !z) || (nit == 2 && !z))) return hipErrorInvalidValue;
+    a.G[0] = p[i].G; a.X1[0] = p[i].X1; a.X2 = p[i].X2 ? p[i].X2 : p[i].X1; a.ngemm = 1; a.Z = p[i].Z; a.z_tile0 = z ? p[i].x1_ks / 2 : 0;
+    a.g_ks = p[i].g_ks; a.o_tiles = (p[i].g_ks + 1) / 2; a.x1_ks = p[i].x1_ks; a.wb_tot = wb_tot; a.slabs = slab;
+    m.kind[i] = 2 * nit + (z ? 1 : 0);
+    m.wg0[i] = wg0;
+    wg0 += nwg[i];
+    p[i].slabs = slab;
+    p[i].nslab = nwg[i];
+    const size_t rows = (size_t)a.o_tiles * 32 + (z ? 32 : 0);
+    slab += (size_t)nwg[i] * rows * (nit * 32 + 1);
+  }
+  m.wg0[n] = wg0;
+  if (slab_end) *slab_end = slab;
+  static std::atomic<unsigned long long> opted{0};
+  constexpr int lds_bytes = 144 * 1024;
+  static_assert(DwbGeom<10, false>::LDS_BYTES <= lds_bytes && DwbGeom<9, true>::LDS_BYTES <= lds_bytes && DwbGeom<8, false>::LDS_BYTES <= lds_bytes &&
+                DwbGeom<4, false>::LDS_BYTES <= lds_bytes && DwbGeom<2, false>::LDS_BYTES <= lds_bytes, "LDS of the multi-product launch");
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_dw_bf16_multi)}, lds_bytes)) return e;
+  hipLaunchKernelGGL(k_dw_bf16_multi, dim3(wg0), dim3(BF_WG), lds_bytes, st, m);
+  return hipGetLastError();
 }
 
 // slab rows [o_first, o_first + o_count), columns [i_first, i_first + i_count) -> dW[o][col0 + i]; last slab column -> db

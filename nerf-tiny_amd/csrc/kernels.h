@@ -258,6 +258,15 @@ hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned 
                                const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st);
 hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned char* const* Xs, int n, int wb_tot, float* slabs, int* nslab,
                                 hipStream_t st);
+// one product of a multi-product launch (small batches: dw_bf16.hip): inputs G, X1 (+ X2) (+ Z); slabs / nslab are filled in
+struct DwBfProd {
+  const unsigned char* G; int g_ks;
+  const unsigned char* X1; int x1_ks;
+  const unsigned char* X2; int x2_ks;
+  const unsigned char* Z;
+  float* slabs; int nslab;
+};
+hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, float** slab_end, hipStream_t st);
 hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count,
                                  float* dW, int ldw, int col0, float* db, hipStream_t st);
 // dW[o][col0 + i - i_first] = sum over slabs of row o_first + o, column i; db[o] likewise from the last slab column

@@ -277,8 +277,9 @@ def test_bf16_training_trajectory_follows_the_emulation(oracle, pkg, dev):
     (nerf.py:468-475; Adam betas (0.9, 0.999), eps 1e-7, the EXP schedule of nerf.py:425-426 with both branches walked), the bf16
     EMULATION (oracle.mlp_bf16 through the oracle's renderer, autograd) + torch.optim.Adam on the CPU against NeRFModel(bf16_mlp) +
     FusedAdam on the GPU, same ray batches and start weights.
-    (a) Teacher-forced: at every step the device evaluates the loss at the EMULATION's current weights: within the bf16 forward bar
-        (1e-2 relative: C_fine's bar in test_forward_bf16) along the whole trajectory.
+    (a) Teacher-forced: at every step the device evaluates the loss at the EMULATION's current weights: within 1e-3 relative along the
+        whole trajectory (a tenth of the bf16 forward bar -- C_fine's 1e-2 in test_forward_bf16; measured 7e-6: the loss is a sum over
+        rays in which the flipped roundings of single hidden units average out).
     (b) Free-running: inside a band computed from the emulation's OWN drift -- its run with every to-be-rounded value jittered by a seeded
         relative 1e-6 (oracle.mlp_bf16_jittered) against its unjittered run: three times the maximum over two seeds per step (floor: the
         forward bar), for the loss curve and for the final weights.
@@ -332,7 +333,7 @@ def test_bf16_training_trajectory_follows_the_emulation(oracle, pkg, dev):
             Cc, Cf = tf(row, col, pb, K)
             e = abs(float(tf.ray_loss(Cc, Cf, Ct.to(dev))) - ref_l[s]) / ref_l[s]
             worst_tf = max(worst_tf, e)
-            assert e <= FWD_BAR, (s, e)
+            assert e <= 0.1 * FWD_BAR, (s, e)
 
     # (b) free-running, bf16; (c) the fp32 device run on the same batches
     def device_run(bf16):
@@ -366,5 +367,5 @@ def test_bf16_training_trajectory_follows_the_emulation(oracle, pkg, dev):
     assert dev_l[-1] < 0.6 * dev_l[0] and ref_l[-1] < 0.6 * ref_l[0] and f32_l[-1] < 0.6 * f32_l[0]  # all three trainers learn
     assert gap < 0.10 and curve_gap < 0.15, (gap, curve_gap)
     print(f"bf16 trajectory: {steps} steps, loss {ref_l[0]:.3f} -> {ref_l[-1]:.3f} (emulation) / {dev_l[-1]:.3f} (device bf16) / {f32_l[-1]:.3f} (device fp32); "
-          f"teacher-forced worst rel {worst_tf:.1e} (bar {FWD_BAR:.0e}); free-running largest |dev - emulation| / bar = {worst:.2f}; the emulation's own "
+          f"teacher-forced worst rel {worst_tf:.1e} (bar {0.1 * FWD_BAR:.0e}); free-running largest |dev - emulation| / bar = {worst:.2f}; the emulation's own "
           f"jitter drift at the last step {band_l[-1] / ref_l[-1]:.1e} rel; fp32-vs-bf16 final-loss gap {gap:.1e}, largest along the curve {curve_gap:.1e}")
