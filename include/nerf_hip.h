@@ -72,6 +72,9 @@ enum {
 /* status word bits (nerf_hip_read_status) */
 enum {
   NERF_HIP_STATUS_RESAMPLE_INDEX = 1 << 0, /* the condition on which nerf.py:251-253 calls exit(0) (quirk Q7) */
+  NERF_HIP_STATUS_PREP_TIMEOUT = 1 << 1,   /* STICKY word only: a block of the one-launch preparation of a bf16-MLP call gave up waiting for
+                                              the weight fold (never seen in practice: the wait is bounded so that a fault cannot hang the GPU;
+                                              the results of that call are wrong) */
 };
 
 /* Limits of this build: 2 <= B, 2 <= Nc <= 1024, 1 <= Nf <= 1024, Nc + Nf <= 2048. */

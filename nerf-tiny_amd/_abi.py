@@ -18,6 +18,7 @@ BF16_MLP = 1 << 2
 WEIGHTS_UNCHANGED = 1 << 3
 SPLIT_MLP = 1 << 4
 STATUS_RESAMPLE_INDEX = 1 << 0
+STATUS_PREP_TIMEOUT = 1 << 1
 
 _p = C.c_void_p
 _PROTOS = {

@@ -58,7 +58,13 @@ size_t wave_blocks(int B, int N) { return (((size_t)B * N + 255) / 256) * 8; }
 // bf16 weight-gradient phase: all products in one or two launches (dw_bf16.hip: k_dw_bf16_multi) up to this many wave blocks -- where the
 // per-product launches' slabs (219 MB per step whatever the batch) and launch boundaries weigh -- and a launch per product beyond.
 // NERF_DW_BF16_MULTI=0 / 1 overrides the choice (A/B measurements only).
-constexpr int DW_BF16_MULTI_MAX_WB = 8192;  // 1,365 rays x (64 + 128)
+// NERF_PREP_BF16=0: the bf16 paths prepare with separate launches (fold, pack, rays; the backward packs its own image) as up to round 3
+// (A/B measurements only)
+bool prep_bf16_disabled() {
+  static const bool off = [] { const char* e = getenv("NERF_PREP_BF16"); return e && atoi(e) == 0; }();
+  return off;
+}
+constexpr int DW_BF16_MULTI_MAX_WB = 5120;  // 853 rays x (64 + 128); measured: 400 rays -25 %, 512 -18 %, 1024 +-0, 2048 +10 %, 4096 +30 %
 bool dw_bf16_multi(int wb_tot) {
   static const int forced = [] { const char* e = getenv("NERF_DW_BF16_MULTI"); return e ? atoi(e) : -1; }();
   return forced >= 0 ? forced != 0 : wb_tot <= DW_BF16_MULTI_MAX_WB;
@@ -287,7 +293,10 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   const Weights24 w = as_w24(weights24);
 
   ProfChain pc;  // the phases below follow each other with nothing in between
-  if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED)) {
+  // bf16-MLP calls: fold, packed image(s) -- a training call's transposed image for the backward chain included -- and the ray records
+  // in ONE launch (prep_bf16.hip) instead of three or four dependent ones
+  const bool one_prep = bf16 && !split && !prep_bf16_disabled();
+  if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED) && !one_prep) {
     ProfScope ps(NERF_HIP_K_PACK, st, &pc);
     if (bf16 || split) HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));  // fp32 W_fold, b_fold for the bf16 / split packers (bf16_common.h)
     if (split) HIP_TRY(launch_pack_weights_split(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_sp), st));
@@ -308,7 +317,20 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ra.b_fold = at<float>(ws, L.fold);
   ra.t_c = at<float>(ws, L.t_c);
   ra.status = at<unsigned>(ws, L.status);  // zeroed by the kernel (the later kernels OR their flags into it)
-  { ProfScope ps(NERF_HIP_K_RAYS, st, &pc); HIP_TRY(launch_rays(ra, st)); }
+  if (one_prep) {
+    const bool pack = !(flags & NERF_HIP_WEIGHTS_UNCHANGED);
+    static std::atomic<unsigned> g_token{0};
+    unsigned token = ++g_token;
+    if (token == 0) token = ++g_token;
+    ProfScope ps(pack ? NERF_HIP_K_PACK : NERF_HIP_K_RAYS, st, &pc);
+    HIP_TRY(launch_prep_bf16(w, at<float>(ws, L.fold), pack ? at<unsigned char>(ws, L.packed_bf) : nullptr, bf16x ? 1 : 0,
+                             pack && save ? at<unsigned char>(ws, L.packed_bf_bwd) : nullptr,
+                             reinterpret_cast<unsigned long long*>(at<unsigned>(ws, L.status) + STATUS_PREP_SYNC_WORD), token,
+                             at<unsigned>(ws, L.status) + STATUS_STICKY_WORD, ra, st));
+  } else {
+    ProfScope ps(NERF_HIP_K_RAYS, st, &pc);
+    HIP_TRY(launch_rays(ra, st));
+  }
 
   FieldArgs fa;
   memset(&fa, 0, sizeof(fa));
@@ -443,7 +465,8 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
   const int wb_c = (int)wave_blocks(B, Nc), wb_tot = wb_c + (int)wave_blocks(B, Nf);
   ProfChain pc;  // the phases below follow each other with nothing in between
   // (the fp32 fold of the forward call is still in the workspace: backward runs on the weights its forward ran on)
-  if (bf16) { ProfScope ps(NERF_HIP_K_PACK, st, &pc); HIP_TRY(launch_pack_weights_bf16_bwd(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf_bwd), st)); }
+  // (bf16: the forward call packed the transposed image of the chain too -- prep_bf16.hip -- unless the one-launch preparation is off)
+  if (bf16 && prep_bf16_disabled()) { ProfScope ps(NERF_HIP_K_PACK, st, &pc); HIP_TRY(launch_pack_weights_bf16_bwd(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf_bwd), st)); }
 
   // 1. merged composite + per-channel sort backward (nerf.py:302-321)
   MergeBwdArgs mb;

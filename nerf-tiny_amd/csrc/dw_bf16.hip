@@ -17,6 +17,7 @@
 // The kernel is HBM-bound by construction (1 KiB of operands per 128 kFLOP): it is paced by the ring, not by the MFMAs.
 #include "bf16_stream.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace nerf {
@@ -358,8 +359,17 @@ hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base
   DwBfMulti m;
   memset(&m, 0, sizeof(m));
   m.n = n;
+  // cost of a product per wave block = its KiB, weighted by how far below the big products' rate its shape streams (small blocks are paced
+  // by the ring's per-block latency: profiles/r03_train_bf16_pmc.json -- 256 x 256 products 5.8 TB/s, layer 4 5.4, the folded product 4.3,
+  // colour head 3.8, layer 0 3.4); NERF_DW_BF16_COST=0: plain bytes (A/B measurements only)
+  static const bool by_cost = [] { const char* e = getenv("NERF_DW_BF16_COST"); return !(e && atoi(e) == 0); }();
   int pieces[DwBfMulti::MAXP], total = 0;
-  for (int i = 0; i < n; ++i) { pieces[i] = p[i].g_ks + p[i].x1_ks + p[i].x2_ks + (p[i].Z ? 2 : 0); total += pieces[i]; }
+  for (int i = 0; i < n; ++i) {
+    const int kib = p[i].g_ks + p[i].x1_ks + p[i].x2_ks + (p[i].Z ? 2 : 0), xks = p[i].x1_ks + p[i].x2_ks;
+    const int pct = !by_cost ? 100 : xks == 4 ? 170 : xks == 8 ? 150 : (xks == 18 && p[i].Z) ? 135 : xks == 20 ? 107 : 100;
+    pieces[i] = kib * pct;
+    total += pieces[i];
+  }
   const int budget = DWB_WGS;
   int nwg[DwBfMulti::MAXP], used = 0;
   for (int i = 0; i < n; ++i) {

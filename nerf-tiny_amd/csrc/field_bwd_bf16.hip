@@ -11,6 +11,7 @@
 // that the ring shrinks to 5 slots (3.5 chunks of look-ahead).  LDS: 72 KiB masks + 80 KiB ring.
 // Gradients are rounded to bf16 where they enter an MFMA (standard mixed precision); sums stay fp32.
 #include "bf16_stream.h"
+#include "bf16_weights.h"
 
 namespace nerf {
 
@@ -211,30 +212,6 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
 // ------------------------------------------------------------------------------------------
 // transposed weight image: fragment (f, ks), lane (i, h), slot s  =  W[out = 16ks + 4h + (s&3) + 8(s>>2)][in = 32f + i]
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bb_weight(const Weights24& w, const float* __restrict__ fold, int frag, int i, int kk) {
-  if (frag < BBS_FOLDT) {  // COLT: d c = W_color^T dz
-    const int f = frag / 4, ks = frag % 4, k = 16 * ks + kk;
-    return k < 3 ? w.p[W_COLOR][(size_t)k * HALF + 32 * f + i] : 0.f;
-  }
-  if (frag < BBS_L7T) {  // FOLDT: 8 k-steps of W_fold^T (W_fold = W_dir[:, 24:] W_pi, [128][256]), then the sigma step (input slot 3)
-    const int q = frag - BBS_FOLDT, f = q / 9, ks = q % 9, k = 16 * ks + kk;
-    if (ks < 8) return fold[HALF + (size_t)k * WIDTH + 32 * f + i];
-    return kk == 3 ? w.p[W_SIGMA][32 * f + i] : 0.f;
-  }
-  if (frag < BBS_G0T) {  // L7T .. L1T (layer 4: hidden columns of the [256][316] matrix)
-    const int r = frag - BBS_L7T, l = 7 - r / 128, q = r % 128, f = q / 16, ks = q % 16;
-    const int ld = (l == 4) ? WIDTH + POINT_DIM : WIDTH;
-    return w.p[2 * l][(size_t)(16 * ks + kk) * ld + 32 * f + i];
-  }
-  if (frag < BBF_NFRAG) {  // d gamma_p, fine pass: tile f = 16 k-steps of W_0^T (input dpre0), then 16 k-steps of W_4[:, 256:]^T (input dpre4)
-    const int q = frag - BBS_G0T, f = q / 32, ks = q % 32, col = 32 * f + i;
-    if (col >= POINT_DIM) return 0.f;
-    if (ks < 16) return w.p[0][(size_t)(16 * ks + kk) * POINT_DIM + col];
-    return w.p[8][(size_t)(16 * (ks - 16) + kk) * (WIDTH + POINT_DIM) + WIDTH + col];
-  }
-  return 0.f;  // padding up to whole chunks
-}
-
 __global__ __launch_bounds__(256) void k_pack_weights_bf16_bwd(const Weights24 w, const float* __restrict__ fold, unsigned char* __restrict__ img) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= BBF_NCHUNK * BF_CHUNK * 64) return;

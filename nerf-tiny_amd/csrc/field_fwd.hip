@@ -19,6 +19,7 @@
 //    behind the current block's 16 MFMAs (1024 cycles), which hides the L2 latency;
 //  * two workgroups per CU (2 x 68 KiB LDS): one's barriers/epilogues hide under the other's MFMAs.
 #include "field_common.h"
+#include "prep_parts.h"
 
 namespace nerf {
 
@@ -76,47 +77,7 @@ __constant__ const SegOffTable kSegOff = make_seg_off_table();
 // every ray's dir_info start vector), fold[128 + o * 256 + k] = W_fold[o][k] = sum_j W_dir[o][24 + j] * W_pi[j][k] (common.h SEG_FOLD).
 // 129 blocks: block o < 128 = row o of W_fold, thread (part, k4): four fp32 fma chains over a quarter of the j range each (the W_dir
 // element of a step is wave-uniform, the W_pi row a coalesced KiB), the quarters added in a fixed order; block 128 = b_fold.
-__global__ __launch_bounds__(256) void k_fold_weights(Weights24 w, float* __restrict__ fold) {
-  __shared__ float4 part_sum[3][64];
-  const int t = threadIdx.x;
-  if (blockIdx.x == HALF) {
-    __shared__ float bsum[HALF];
-    const int o = t & (HALF - 1), half = t >> 7;
-    const float* dr = w.p[W_DIR] + (size_t)o * (WIDTH + DIR_DIM) + DIR_DIM + half * (WIDTH / 2);
-    const float* bp = w.p[B_PI] + half * (WIDTH / 2);
-    float s = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < WIDTH / 2; ++j) s = __builtin_fmaf(dr[j], bp[j], s);
-    if (half) bsum[o] = s;
-    __syncthreads();
-    if (!half) fold[o] = s + bsum[o];
-    return;
-  }
-  const int o = blockIdx.x, k0 = 4 * (t & 63);
-  const int part = __builtin_amdgcn_readfirstlane(t >> 6);
-  const float* dr = w.p[W_DIR] + (size_t)o * (WIDTH + DIR_DIM) + DIR_DIM + part * (WIDTH / 4);
-  const float* pc = w.p[W_PI] + (size_t)part * (WIDTH / 4) * WIDTH + k0;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-  for (int j = 0; j < WIDTH / 4; ++j) {
-    const float d = dr[j];
-    const float4 q = *reinterpret_cast<const float4*>(pc + (size_t)j * WIDTH);
-    acc.x = __builtin_fmaf(d, q.x, acc.x);
-    acc.y = __builtin_fmaf(d, q.y, acc.y);
-    acc.z = __builtin_fmaf(d, q.z, acc.z);
-    acc.w = __builtin_fmaf(d, q.w, acc.w);
-  }
-  if (part) part_sum[part - 1][t & 63] = acc;
-  __syncthreads();
-  if (part == 0) {
-    const float4 p1 = part_sum[0][t], p2 = part_sum[1][t], p3 = part_sum[2][t];
-    acc.x = (acc.x + p1.x) + (p2.x + p3.x);
-    acc.y = (acc.y + p1.y) + (p2.y + p3.y);
-    acc.z = (acc.z + p1.z) + (p2.z + p3.z);
-    acc.w = (acc.w + p1.w) + (p2.w + p3.w);
-    *reinterpret_cast<float4*>(fold + HALF + (size_t)o * WIDTH + k0) = acc;
-  }
-}
+__global__ __launch_bounds__(256) void k_fold_weights(Weights24 w, float* __restrict__ fold) { fold_block(w, fold, blockIdx.x); }
 
 hipError_t launch_fold_weights(const Weights24& w, float* fold, hipStream_t st) {
   hipLaunchKernelGGL(k_fold_weights, dim3(HALF + 1), dim3(256), 0, st, w, fold);

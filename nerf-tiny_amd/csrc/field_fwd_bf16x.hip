@@ -17,22 +17,12 @@
 // same bf16 operands but sum in a different order, so an inference and a training forward of the same batch agree to
 // fp32 rounding before the next bf16 rounding, not bit for bit.
 #include "bf16_stream.h"
+#include "bf16_weights.h"
 
 namespace nerf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// stream segments (16-row tiles x 32-wide k-steps), first fragment of each
-constexpr int BXS_L0 = 0;      // 16 tiles x 2
-constexpr int BXS_L1 = 32;     // 16 x 8, likewise L2, L3
-constexpr int BXS_L4 = 416;    // 16 x (8 hidden + 2 gamma_p)
-constexpr int BXS_L5 = 576;    // 16 x 8, likewise L6, L7
-constexpr int BXS_SIG = 960;   // 1 x 8: row 0 = sigma_layer (on h7)
-constexpr int BXS_DIR = 968;   // 8 x (1 gamma_d + 8 h7 through W_fold: point_info folded into dir_info, bf16_common.h)
-constexpr int BXS_COL = 1040;  // 1 x 4
-constexpr int BX_NFRAG = 1044;
-constexpr int BX_NCHUNK = (BX_NFRAG + BF_CHUNK - 1) / BF_CHUNK;  // 66 (the last chunk is padded)
-static_assert((size_t)BF_BIAS_BYTES + (size_t)BX_NCHUNK * BF_CHUNK * BF_FRAG_BYTES <= BF_IMAGE_BYTES, "shares the workspace region of the 32x32x16 image");
 // bias block: the float layout of the 32x32x16 image (bf16_common.h), addressed per 16 features
 constexpr int BXB_SIGMA = 32 * BFB_SIGMA, BXB_DIR = 32 * BFB_DIR, BXB_COL = 32 * BFB_COL;
 
@@ -250,39 +240,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16x(const FieldAr
 // ------------------------------------------------------------------------------------------
 // weight image: fragment (tile T, k-step s), lane (i, q), slot j = W[16T + i][32s + 16 (j >> 2) + 4q + (j & 3)]
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bx_weight(const Weights24& w, const float* __restrict__ fold, int frag, int i, int kk /* input feature inside the k-step */) {
-  if (frag < BXS_L1) {  // L0
-    const int T = frag / 2, s = frag % 2, k = 32 * s + kk;
-    return k < POINT_DIM ? w.p[0][(size_t)(16 * T + i) * POINT_DIM + k] : 0.f;
-  }
-  if (frag < BXS_L4) {  // L1..L3
-    const int r = frag - BXS_L1, l = 1 + r / 128, x = r % 128, T = x / 8, s = x % 8;
-    return w.p[2 * l][(size_t)(16 * T + i) * WIDTH + 32 * s + kk];
-  }
-  if (frag < BXS_L5) {  // L4: [256][316] = cat(hidden, gamma_p)
-    const int x = frag - BXS_L4, T = x / 10, s = x % 10, k = 32 * s + kk;
-    return (k < WIDTH + POINT_DIM) ? w.p[8][(size_t)(16 * T + i) * (WIDTH + POINT_DIM) + k] : 0.f;
-  }
-  if (frag < BXS_SIG) {  // L5..L7
-    const int r = frag - BXS_L5, l = 5 + r / 128, x = r % 128, T = x / 8, s = x % 8;
-    return w.p[2 * l][(size_t)(16 * T + i) * WIDTH + 32 * s + kk];
-  }
-  if (frag < BXS_DIR) {  // the sigma tile on h7
-    const int s = frag - BXS_SIG, k = 32 * s + kk;
-    return i == 0 ? w.p[W_SIGMA][k] : 0.f;
-  }
-  if (frag < BXS_COL) {  // dir_info: gamma_d columns of W_dir (24 -> 32), then W_fold = W_dir[:, 24:] W_pi on h7
-    const int x = frag - BXS_DIR, T = x / 9, s = x % 9;
-    if (s == 0) return kk < DIR_DIM ? w.p[W_DIR][(size_t)(16 * T + i) * (WIDTH + DIR_DIM) + kk] : 0.f;
-    return fold[HALF + (size_t)(16 * T + i) * WIDTH + 32 * (s - 1) + kk];
-  }
-  if (frag < BX_NFRAG) {  // colour head
-    const int s = frag - BXS_COL, k = 32 * s + kk;
-    return i < 3 ? w.p[W_COLOR][(size_t)i * HALF + k] : 0.f;
-  }
-  return 0.f;  // padding of the last chunk
-}
-
 // the bias block is the 32x32x16 image's (same float layout); only the fragments differ
 __global__ __launch_bounds__(256) void k_pack_weights_bf16x(const Weights24 w, const float* __restrict__ fold, unsigned char* __restrict__ img) {
   const int gid = blockIdx.x * 256 + threadIdx.x;

@@ -120,6 +120,11 @@ size_t split_image_bytes();
 hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 hipError_t launch_field_fwd_split(const FieldArgs& a, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
+// bf16 paths: fold + packed image(s) + ray records in ONE launch (prep_bf16.hip).  img_fwd: forward image (fwd_form 0: 32x32x16 stream,
+// 1: 16x16x32) or null = weights unchanged; img_bwd: transposed image of the backward chain or null; sync: an 8-byte word of the workspace
+// that no other kernel writes; token: unique per call, never 0; sticky: the sticky status word (timeout report) or null
+hipError_t launch_prep_bf16(const Weights24& w, float* fold, unsigned char* img_fwd, int fwd_form, unsigned char* img_bwd,
+                            unsigned long long* sync, unsigned token, unsigned* sticky, const RaysArgs& rays, hipStream_t st);
 hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st);
 size_t merge_lds_bytes(int P);
 hipError_t launch_merge(const MergeArgs& a, hipStream_t st);

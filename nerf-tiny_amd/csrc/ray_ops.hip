@@ -8,6 +8,7 @@
 // the channel sorts are bitonic networks in LDS.  Built with -ffp-contract=off: the arithmetic order is
 // the reference's (SURVEY.md 8a SPEC); fused multiply-adds appear only where written as fmaf.
 #include "kernels.h"
+#include "prep_parts.h"
 
 namespace nerf {
 
@@ -46,67 +47,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __global__ __launch_bounds__(128) void k_rays(const RaysArgs a) {
   __shared__ float gd[DIR_DIM];
-  const int ray = blockIdx.x, tid = threadIdx.x;
-  if (a.status && ray == 0 && tid < STATUS_STICKY_WORD) a.status[tid] = 0u;  // the forward's status words start clean (instead of a memset node of their own); the sticky ones stay
-  const float* pb = a.pb + (size_t)ray * 17;
-  // x <- row, y <- column (quirk Q2)
-  const float x = (float)a.row[ray], y = (float)a.col[ray];
-  float p[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) p[j] = (x * a.K[j] + y * a.K[3 + j]) + a.K[6 + j];
-  // F.normalize (nerf.py:193): ATen's CPU 2-norm accumulates acc = fma(v, v, acc) in fp32 and takes the
-  // square root in double; clamp_min(1e-12); true division.
-  const float ss = __builtin_fmaf(p[2], p[2], __builtin_fmaf(p[1], p[1], p[0] * p[0]));
-  float nrm = (float)sqrt((double)ss);
-  nrm = fmaxf(nrm, 1e-12f);
-  float d[3], dw[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) d[j] = p[j] / nrm;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) dw[c] = (pb[5 * c] * d[0] + pb[5 * c + 1] * d[1]) + pb[5 * c + 2] * d[2];
-  const float near = pb[15], far = pb[16];
-  const float step = (far - near) / (float)(a.Nc - 1);
-  if (tid == 0) {
-    if (a.rayf) {
-      float* rf = a.rayf + (size_t)ray * RAYF;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) rf[RF_R + 3 * c + k] = pb[5 * c + k];
-        rf[RF_O + c] = pb[5 * c + 3];
-        rf[RF_DCAM + c] = d[c];
-        rf[RF_DWRD + c] = dw[c];
-      }
-      rf[RF_NEAR] = near;
-      rf[RF_FAR] = far;
-      rf[RF_STEP] = step;
-      rf[RF_DELTA] = (far - near) / (float)a.Nc;  // quirk Q5 (nerf.py:293)
-      rf[22] = 0.f;
-      rf[23] = 0.f;
-    }
-    if (a.d_cam)
-      for (int c = 0; c < 3; ++c) a.d_cam[(size_t)ray * 3 + c] = d[c];
-    if (a.d_wrd)
-      for (int c = 0; c < 3; ++c) a.d_wrd[(size_t)ray * 3 + c] = dw[c];
-  }
-  if (a.t_c) {
-    for (int i = tid; i < a.Nc; i += 128) a.t_c[(size_t)ray * a.Nc + i] = (i == a.Nc - 1) ? far : ((float)i * step + near);
-  }
-  if (a.dvec) {
-    if (tid < 12) {
-      const int c = tid >> 2, l = tid & 3;
-      const float ph = dw[c] * __uint_as_float(kFreqDirBits[l]);
-      gd[c * 8 + 2 * l] = sinf(ph);
-      gd[c * 8 + 2 * l + 1] = cosf(ph);
-    }
-    __syncthreads();
-    const float* wr = a.w_dir + (size_t)tid * (WIDTH + DIR_DIM);
-    float s = a.b_dir[tid];
-#pragma unroll
-    for (int k = 0; k < DIR_DIM; ++k) s = __builtin_fmaf(wr[k], gd[k], s);
-    if (a.b_fold) s += a.b_fold[tid];  // point_info's bias through dir_info's feature columns (common.h SEG_FOLD)
-    a.dvec[(size_t)ray * HALF + tid] = s;
-  }
+  ray_block(a, blockIdx.x, threadIdx.x, gd);
 }
 
 // ---------------------------------------------------------------------------------------------

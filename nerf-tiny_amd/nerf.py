@@ -299,6 +299,9 @@ class NeRFModel(nn.Module):
             st = C.c_uint32(0)
             _abi.check(_abi.lib().nerf_hip_read_status_sticky(ws.data_ptr(), ws.numel(), C.byref(st), 1 if clear else 0,
                                                               torch.cuda.current_stream(ws.device).cuda_stream))
+            if st.value & _abi.STATUS_PREP_TIMEOUT:
+                raise _abi.NerfHipError("a bf16-MLP call's one-launch preparation gave up waiting for the weight fold (prep_bf16.hip): the results "
+                                        "of that call are wrong")
             hit = hit or bool(st.value & _abi.STATUS_RESAMPLE_INDEX)
         return hit
 

@@ -369,3 +369,51 @@ def test_bf16_training_trajectory_follows_the_emulation(oracle, pkg, dev):
     print(f"bf16 trajectory: {steps} steps, loss {ref_l[0]:.3f} -> {ref_l[-1]:.3f} (emulation) / {dev_l[-1]:.3f} (device bf16) / {f32_l[-1]:.3f} (device fp32); "
           f"teacher-forced worst rel {worst_tf:.1e} (bar {0.1 * FWD_BAR:.0e}); free-running largest |dev - emulation| / bar = {worst:.2f}; the emulation's own "
           f"jitter drift at the last step {band_l[-1] / ref_l[-1]:.1e} rel; fp32-vs-bf16 final-loss gap {gap:.1e}, largest along the curve {curve_gap:.1e}")
+
+
+def _variant(tmp_path, name, env_extra, B=96):
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI")}
+    env.update(env_extra)
+    out = str(tmp_path / (name + ".pt"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "bf16_variant_dump.py"), out, str(B)], capture_output=True, text=True,
+                       env=env, timeout=400)
+    assert r.returncode == 0 and "DUMP-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    return torch.load(out, weights_only=False)
+
+
+@pytest.mark.timeout(900)
+def test_one_launch_preparation_equals_separate_launches(tmp_path):
+    """prep_bf16.hip: fold + packed image(s) + ray records of a bf16-MLP call in ONE launch, the packers of folded fragments waiting for the
+    fold blocks inside the launch (agent-scope release / acquire on a {token, count} word).  Against the round-3 structure (fold, pack, rays
+    as separate launches, the backward packing its own image: NERF_PREP_BF16=0, a process of its own -- the switch is read once): the packed
+    images, ray records and coarse depths byte for byte, the outputs and -- with the same weight-gradient structure on both sides -- every
+    gradient bit for bit; no timeout reported; the frozen rendering loop (rays only, image reused) gives the inference call's pixels."""
+    new = _variant(tmp_path, "prep1", {"NERF_DW_BF16_MULTI": "1"})
+    old = _variant(tmp_path, "prep0", {"NERF_PREP_BF16": "0", "NERF_DW_BF16_MULTI": "1"})
+    assert new["sticky"] == 0 and old["sticky"] == 0
+    for k in ("train_packed_bf", "infer_packed_bf", "rayf", "t_c", "Cc", "Cf", "Ic", "If", "Fc", "Ff"):
+        assert torch.equal(new[k], old[k]), k
+    assert new["loss"] == old["loss"]
+    for a, b in zip(new["grads"], old["grads"]):
+        assert torch.equal(a, b)
+    assert torch.equal(new["Fc"], new["Ic"]) and torch.equal(new["Ff"], new["If"])
+
+
+@pytest.mark.timeout(900)
+def test_weight_gradients_in_one_launch_equal_a_launch_per_product(tmp_path):
+    """dw_bf16.hip k_dw_bf16_multi (small batches: every product of the step in ONE launch, the workgroups dealt out by bytes) against a
+    launch per product (NERF_DW_BF16_MULTI=0): the same sums over the same samples split into a different number of slabs -- equal to fp32
+    summation order (1e-5 of each tensor's norm), forward untouched."""
+    for B in (96, 333):  # 333 rays: more wave blocks than workgroups for some products, fewer for others
+        one = _variant(tmp_path, f"multi1_{B}", {"NERF_DW_BF16_MULTI": "1"}, B)
+        per = _variant(tmp_path, f"multi0_{B}", {"NERF_DW_BF16_MULTI": "0"}, B)
+        assert torch.equal(one["Cc"], per["Cc"]) and torch.equal(one["Cf"], per["Cf"]) and one["loss"] == per["loss"]
+        for i, (a, b) in enumerate(zip(one["grads"], per["grads"])):
+            assert torch.isfinite(a).all()
+            assert float((a.double() - b.double()).norm()) <= 1e-5 * float(b.double().norm()) + 1e-12, (B, i)

@@ -92,16 +92,28 @@ def test_data_parallel_runner_single_rank_rccl_equals_plain_runner(tmp_path, bf1
     """NeRFRunner under a launcher.  One rank over a REAL RCCL group (the collective is the identity): the data-
     parallel loop -- sharded sampler, gradients in the flat bucket, overlapped all-reduce, fused Adam on the views, rank 0 logging and
     checkpointing, display() through render_rows_sharded + gather_rows -- must leave bit-identical weights, losses and frames to the
-    plain single-process runner (same kernels, same order of the same batches)."""
+    plain single-process runner (same kernels, same order of the same batches) in fp32; bf16: see below."""
     import torch
 
     extra = ("--bf16",) if bf16 else ()
     plain = _run_ranks(0, str(tmp_path / "plain"), extra)
     dp = _run_ranks(1, str(tmp_path / "dp1"), extra + ("--force-dist",))
     assert plain["distributed"] is False and dp["distributed"] is True and dp["ranks"] == 1 and dp["local_rays"] == 256
-    assert plain["losses"] == dp["losses"] and len(dp["losses"]) == 6
-    assert torch.equal(plain["weights"], dp["weights"])
-    assert torch.equal(plain["frame"], dp["frame"])
+    assert len(dp["losses"]) == 6 and plain["losses"][0] == dp["losses"][0]
+    if not bf16:
+        assert plain["losses"] == dp["losses"]
+        assert torch.equal(plain["weights"], dp["weights"])
+        assert torch.equal(plain["frame"], dp["frame"])
+    else:
+        # bf16 weight gradients of a small batch: ONE launch for all products, or -- with the overlap's early event -- one for
+        # point_layer[0..7] and one for the rest; the workgroups (= slabs) per product differ between the two, i.e. the same sums in
+        # another order.  Adam turns last-bit differences into +-lr updates (tests/test_gpu_train.py: trajectory test), so from the
+        # second step on the two runs are two correct trainers, not the same bits
+        for a, b in zip(plain["losses"], dp["losses"]):
+            assert abs(a - b) <= 3e-2 * abs(a), (plain["losses"], dp["losses"])
+        d = (plain["weights"] - dp["weights"]).abs()
+        assert float(d.max()) <= 2 * 1e-3 * 6 + 1e-6 and float(d.mean()) < 1e-3
+        assert float((plain["frame"] - dp["frame"]).abs().max()) < 0.1
     assert len(dp["ckpts"]) == 2 and dp["ckpts"][-1].endswith("_5.pkl") and dp["images"] == 3
 
 

@@ -348,8 +348,10 @@ def test_plain_loop_in_bucket_mode_needs_no_consume_call(oracle, pkg, dev):
         if use_bucket:
             m.grad_bucket = pkg.parallel.GradBucket(m.network.parameters())
         for it in range(4):
-            if it % 2 == 0:
-                opt.zero_grad(set_to_none=True)   # the runner's form; every other step relies on FusedAdam.step's release alone
+            if it % 2 == 0 or not use_bucket:
+                # the runner's form.  In bucket mode every other step relies on FusedAdam.step's release alone (the kernels OVERWRITE the
+                # views); without a bucket autograd ACCUMULATES into an existing p.grad, so that loop must drop it every time
+                opt.zero_grad(set_to_none=True)
             Cc, Cf = m(row, col, pb, K)
             m.ray_loss(Cc, Cf, C_true.to(dev)).backward()
             if use_bucket:

@@ -1,0 +1,74 @@
+"""Child process of tests/test_gpu_bf16.py: one bf16-MLP train step and one inference forward on fixed inputs, everything that the
+library's launch-structure switches could change dumped to a file.  The switches are environment variables read once per process
+(NERF_PREP_BF16: one-launch preparation vs separate fold / pack / rays launches; NERF_DW_BF16_MULTI: all weight-gradient products in one
+launch vs a launch per product), so each variant needs a process of its own.
+
+    [NERF_PREP_BF16=0] [NERF_DW_BF16_MULTI=0|1] python tests/tools/bf16_variant_dump.py OUT.pt [B]
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import torch
+
+import nerf_oracle as O
+import nerf_tiny_amd as P
+from nerf_tiny_amd import _abi
+
+
+def main():
+    out = sys.argv[1]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 96
+    Nc, Nf = 64, 128
+    dev = torch.device("cuda:0")
+    row, col, pb, K, Ct = O.fern_inputs(B, seed=13)
+    w = O.make_weights(5, sharp=True)
+    m = P.NeRFModel(Nc, Nf, B)
+    m.load_state_dict(w)
+    m = m.to(dev)
+    m.bf16_mlp = True
+    res = {}
+    # training call: forward image (32x32x16 stream + bias block), transposed image, ray records, gradients
+    Cc, Cf = m(row, col, pb, K)
+    ws = m.last_workspace
+    flags = _abi.SAVE_FOR_BACKWARD | _abi.BF16_MLP
+
+    def region(name, nbytes, f=flags, w_=None):
+        off = C.c_size_t(0)
+        _abi.check(_abi.lib().nerf_hip_ws_offset(B, Nc, Nf, f, name.encode(), C.byref(off)))
+        return (w_ if w_ is not None else ws)[off.value: off.value + nbytes].clone().cpu()
+
+    img_bytes = 16384 + 1056 * 1024
+    res["train_packed_bf"] = region("packed_bf", img_bytes)
+    res["rayf"] = region("rayf", B * 24 * 4)
+    res["t_c"] = region("t_c", B * Nc * 4)
+    loss = m.ray_loss(Cc, Cf, Ct.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    res["Cc"], res["Cf"], res["loss"] = Cc.detach().cpu(), Cf.detach().cpu(), float(loss.detach())
+    res["grads"] = [p.grad.detach().cpu() for p in m.network.parameters()]
+    # inference call: the 16x16x32 image
+    with torch.no_grad():
+        Ic, If = m(row, col, pb, K)
+    wsi = m.last_workspace
+    res["infer_packed_bf"] = region("packed_bf", img_bytes, _abi.BF16_MLP, wsi)
+    res["Ic"], res["If"] = Ic.cpu(), If.cpu()
+    # frozen rendering loop: the second call reuses the image and only makes the ray records
+    with torch.no_grad(), m.frozen_weights():
+        m(row, col, pb, K)
+        Fc, Ff = m(row, col, pb, K)
+    res["Fc"], res["Ff"] = Fc.cpu(), Ff.cpu()
+    st = C.c_uint32(0)
+    _abi.check(_abi.lib().nerf_hip_read_status_sticky(ws.data_ptr(), ws.numel(), C.byref(st), 0, torch.cuda.current_stream(dev).cuda_stream))
+    res["sticky"] = int(st.value)
+    res["env"] = {k: os.environ.get(k) for k in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI")}
+    torch.save(res, out)
+    print("DUMP-OK", res["env"], flush=True)
+
+
+if __name__ == "__main__":
+    main()
