@@ -352,8 +352,13 @@ def rooflines(leg, prof, b_local, steps):
         return blk, None
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
     fwd_key = (["k_field_fwd_bf16<true>"] if leg.train else ["k_field_fwd_bf16x<2, 8>"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
-    fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
-               FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)
+    if "render_pair" in prof:  # small bf16-MLP inference batches: ONE launch holds both field passes and both composites of every ray pair
+        fwd = mfma("k_render_pair_bf16x (the whole forward of a ray pair per workgroup: both field passes, coarse composite + resampling, merge + sorts + "
+                   "composite in one launch)", ("render_pair",), FLOP_PER_SAMPLE * b_local * (NC + NF), fwd_key, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)
+        fwd["traffic"] = None  # (no PMC pass of this kernel is committed)
+    else:
+        fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
+                   FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)
     fwd["note"] = ("achieved / frac count the FLOPs the kernel EXECUTES (8/9 of the reference network's: point_info folded into dir_info, "
                    "DESIGN.md 3a) -- the MFMA pipe's side, the figure the MFMA-busy counter corroborates; achieved_algorithmic / frac_algorithmic "
                    "price the reference graph's FLOPs (SURVEY.md 8d) over the same time")

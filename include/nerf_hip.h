@@ -163,7 +163,9 @@ enum {
   NERF_HIP_K_PACK = 0, NERF_HIP_K_RAYS = 1, NERF_HIP_K_FIELD_COARSE = 2, NERF_HIP_K_COARSE = 3,
   NERF_HIP_K_FIELD_FINE = 4, NERF_HIP_K_MERGE = 5,
   NERF_HIP_K_BWD_MERGE = 6, NERF_HIP_K_BWD_FIELD_FINE = 7, NERF_HIP_K_BWD_COARSE = 8,
-  NERF_HIP_K_BWD_FIELD_COARSE = 9, NERF_HIP_K_BWD_DW = 10, NERF_HIP_K_COUNT = 11
+  NERF_HIP_K_BWD_FIELD_COARSE = 9, NERF_HIP_K_BWD_DW = 10,
+  NERF_HIP_K_RENDER_PAIR = 11, /* small bf16-MLP inference batches: both field passes and both composites of a ray pair in ONE launch */
+  NERF_HIP_K_COUNT = 12
 };
 int nerf_hip_profile_begin(int max_launches);
 int nerf_hip_profile_end(double* ms_sum, int* count, int n_kernels);

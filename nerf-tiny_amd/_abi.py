@@ -82,7 +82,7 @@ def ws_bytes(B: int, Nc: int, Nf: int, flags: int) -> int:
 
 
 KERNEL_NAMES = ("pack_weights", "rays", "field_fwd_coarse", "coarse_composite", "field_fwd_fine", "merge_composite",
-                "bwd_merge", "bwd_field_fine", "bwd_coarse", "bwd_field_coarse", "bwd_dw")
+                "bwd_merge", "bwd_field_fine", "bwd_coarse", "bwd_field_coarse", "bwd_dw", "render_pair")
 
 
 def profile_begin(max_launches: int) -> None:

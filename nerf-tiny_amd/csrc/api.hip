@@ -64,6 +64,13 @@ bool prep_bf16_disabled() {
   static const bool off = [] { const char* e = getenv("NERF_PREP_BF16"); return e && atoi(e) == 0; }();
   return off;
 }
+// bf16-MLP inference: the ray-pair kernel up to this many rays (one workgroup per pair: at most two rounds over the 256 CUs).
+// NERF_PAIR_BF16=0 / 1 overrides the choice (A/B measurements only)
+constexpr int PAIR_BF16_MAX_RAYS = 1024;
+bool pair_bf16(int B) {
+  static const int forced = [] { const char* e = getenv("NERF_PAIR_BF16"); return e ? atoi(e) : -1; }();
+  return forced >= 0 ? forced != 0 : B <= PAIR_BF16_MAX_RAYS;
+}
 constexpr int DW_BF16_MULTI_MAX_WB = 5120;  // 853 rays x (64 + 128); measured: 400 rays -25 %, 512 -18 %, 1024 +-0, 2048 +10 %, 4096 +30 %
 bool dw_bf16_multi(int wb_tot) {
   static const int forced = [] { const char* e = getenv("NERF_DW_BF16_MULTI"); return e ? atoi(e) : -1; }();
@@ -126,7 +133,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
   L.packed = take((size_t)PACKED_ALL_F4 * 16);
   if (flags & NERF_HIP_BF16_MLP) L.packed_bf = take(BF_IMAGE_BYTES);
   if ((flags & NERF_HIP_SPLIT_MLP) && !(flags & NERF_HIP_BF16_MLP)) L.packed_sp = take(split_image_bytes());
-  L.fold = take(FOLD_FLOATS * 4);
+  L.fold = take((FOLD_FLOATS + PREP_READY_WORDS) * 4);  // + the "fold row o is out" words of the one-launch preparation (prep_bf16.hip)
   L.rayf = take(b * RAYF * 4);
   L.dvec = take(b * HALF * 4);
   L.t_c = take(b * Nc * 4);
@@ -325,7 +332,7 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     ProfScope ps(pack ? NERF_HIP_K_PACK : NERF_HIP_K_RAYS, st, &pc);
     HIP_TRY(launch_prep_bf16(w, at<float>(ws, L.fold), pack ? at<unsigned char>(ws, L.packed_bf) : nullptr, bf16x ? 1 : 0,
                              pack && save ? at<unsigned char>(ws, L.packed_bf_bwd) : nullptr,
-                             reinterpret_cast<unsigned long long*>(at<unsigned>(ws, L.status) + STATUS_PREP_SYNC_WORD), token,
+                             reinterpret_cast<unsigned*>(at<float>(ws, L.fold) + FOLD_FLOATS), token,
                              at<unsigned>(ws, L.status) + STATUS_STICKY_WORD, ra, st));
   } else {
     ProfScope ps(NERF_HIP_K_RAYS, st, &pc);
@@ -358,6 +365,21 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     } else {
       fa.save = at<float>(ws, L.save); fa.masks = at<uint16_t>(ws, L.masks);
     }
+  }
+  // SMALL bf16-MLP inference batches at the shipped sample counts: ONE launch renders every ray pair end to end (field_fwd_bf16x.hip:
+  // k_render_pair_bf16x -- both field passes, coarse composite + resampling, merge + sorts + composite; bit-identical pixels)
+  if (bf16x && Nc == 64 && Nf == 128 && pair_bf16(B)) {
+    PairArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.wbf = at<unsigned char>(ws, L.packed_bf); pa.rayf = at<float>(ws, L.rayf); pa.t_c = at<float>(ws, L.t_c); pa.B = B;
+    if (ray0_near_far) { pa.ray0_override = 1; pa.near0 = ray0_near_far[0]; pa.far0 = ray0_near_far[1]; }
+    pa.last = last_delta; pa.C_coarse = C_coarse; pa.C_fine = C_fine;
+    pa.status = at<uint32_t>(ws, L.status); pa.sticky = at<uint32_t>(ws, L.status) + STATUS_STICKY_WORD;
+    pa.sig_c = at<float>(ws, L.sig_c); pa.rgb_c = at<float>(ws, L.rgb_c); pa.w_c = at<float>(ws, L.w_c); pa.t_f = at<float>(ws, L.t_f);
+    pa.sig_f = at<float>(ws, L.sig_f); pa.rgb_f = at<float>(ws, L.rgb_f);
+    ProfScope ps(NERF_HIP_K_RENDER_PAIR, st, &pc);
+    HIP_TRY(launch_render_pair_bf16x(pa, st));
+    return NERF_HIP_OK;
   }
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
   auto field = [&](const FieldArgs& f) { return split ? launch_field_fwd_split(f, st) : bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };

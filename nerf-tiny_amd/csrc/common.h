@@ -15,7 +15,6 @@ constexpr int L_DIR = 4;
 constexpr int HALF = 128;       // width of the colour branch (nerf.py:98)
 constexpr int TM = 64;          // samples per workgroup tile of the field kernels
 constexpr int STATUS_STICKY_WORD = 32;  // status region = 64 u32 words: [0, 32) cleared by every forward, [32, 64) only by the caller (nerf_hip_read_status_sticky)
-constexpr int STATUS_PREP_SYNC_WORD = 48;  // u32 words 48, 49 of the status region: the {token, count} word of prep_bf16.hip
 constexpr int DBG_WORDS = 16384;   // u64 words of the workspace's diagnostic area (make stamps)
 constexpr int DUMP_ROWS = 64;   // extra rows behind every saved tensor / gradient buffer: lanes past the end of a pass store there, unpredicated
 constexpr int RAYF = 24;        // floats per ray record

@@ -18,6 +18,7 @@
 // fp32 rounding before the next bf16 rounding, not bit for bit.
 #include "bf16_stream.h"
 #include "bf16_weights.h"
+#include "ray_parts.h"
 
 namespace nerf {
 
@@ -95,39 +96,16 @@ __device__ __forceinline__ void bx_segment(const BfCtx& c, u32x4 (&fr)[BF_D], Ac
   });
 }
 
-template <int NH, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16x(const FieldArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  using S = typename BxStreamOf<WAVES>::type;
+// One pass of the field MLP over the wave's 16 NH samples, the weight stream S running through the workgroup's LDS ring once: inputs =
+// this lane's sample points p[h] and world directions dw[h]; `mid(spre)` is called between the dir_info and the colour segments with the
+// sigma pre-activations (valid on the lanes with q == 0: lane n = sample n of group h); on return cpre[h][0..2] are the colour head's
+// pre-activations (same lanes).  Every wave of the workgroup must call it (one barrier per chunk).  S::HAS_BIAS = false: the bias block is
+// already in LDS (a second pass of the same kernel).
+template <class S, int NH, class Mid>
+__device__ __forceinline__ void bx_field_pass(const BfCtx& c, unsigned char* lds, const float (&p)[NH][3], const float (&dw)[NH][3], Mid&& mid,
+                                              float (&cpre)[NH][3]) {
   using Acc = AccN<NH>;
-  BfCtx c;
-  c.wimg = a.wbf;
-  c.lds = lds;
-  c.lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
-  c.lane = threadIdx.x & 63;
-  c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = c.lane, n = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * (16 * NH * WAVES) + c.wv * (16 * NH);
-
-  // ---- ordinary loads first: this lane's NH samples (n, 16 + n, ... of the wave's 16 NH)
-  int ms[NH];
-  bool valid[NH];
-  float p[NH][3], dw[NH][3];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    ms[h] = m0 + 16 * h + n;
-    valid[h] = ms[h] < a.M;
-    const int mc = valid[h] ? ms[h] : a.M - 1;
-    const float* rf = a.rayf + (size_t)(mc / a.N) * RAYF;
-    sample_point(rf, a.t[mc], p[h]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) dw[h][i] = rf[RF_DWRD + i];
-  }
-#pragma unroll
-  for (int h = 0; h < NH; ++h)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p[h][i]), "+v"(dw[h][i]));
-
+  const int q = c.lane >> 4;
   bf_stream_start<S>(c);
 
   // ---- encodings straight into B-operand registers: k-step s, slot pair (j, j+1) = (sin, cos) pair
@@ -163,7 +141,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16x(const FieldAr
 
   // the direction encodings are needed 1,100 fragments later: parked in the 16 KiB of LDS behind the ring (32 bytes per lane)
   // instead of 8 registers the allocator would spill to scratch
-  u32x4* const gd_park = reinterpret_cast<u32x4*>(lds + BF_LDS_BYTES) + NH * threadIdx.x;
+  u32x4* const gd_park = reinterpret_cast<u32x4*>(lds + BF_LDS_BYTES) + NH * (c.wv * 64 + c.lane);
 #pragma unroll
   for (int h = 0; h < NH; ++h) gd_park[h] = gd[h][0];
 
@@ -216,25 +194,280 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16x(const FieldAr
     for (int h = 0; h < NH; ++h) gd[h][0] = back[h];
   }
   bx_segment<S, NH, BXS_DIR, 8, 1, 8, BXB_DIR, 1, BXB_COL>(c, fr, acc, gd, Y, relu_to(X), sig_epi);
-  // (sample indices are re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing to keep alive or spill)
+  mid(spre);
+  // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
+  bx_segment<S, NH, BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X), 7));
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) cpre[h][ch] = acc[1].c[h][ch];
+}
+
+template <int NH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16x(const FieldArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  using S = typename BxStreamOf<WAVES>::type;
+  BfCtx c;
+  c.wimg = a.wbf;
+  c.lds = lds;
+  c.lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
+  c.lane = threadIdx.x & 63;
+  c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = c.lane, n = lane & 15;
+  const int m0 = blockIdx.x * (16 * NH * WAVES) + c.wv * (16 * NH);
+
+  // ---- ordinary loads first: this lane's NH samples (n, 16 + n, ... of the wave's 16 NH)
+  int ms[NH];
+  bool valid[NH];
+  float p[NH][3], dw[NH][3];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    ms[h] = m0 + 16 * h + n;
+    valid[h] = ms[h] < a.M;
+    const int mc = valid[h] ? ms[h] : a.M - 1;
+    const float* rf = a.rayf + (size_t)(mc / a.N) * RAYF;
+    sample_point(rf, a.t[mc], p[h]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dw[h][i] = rf[RF_DWRD + i];
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p[h][i]), "+v"(dw[h][i]));
+
+  float cpre[NH][3];
+  bx_field_pass<S, NH>(c, lds, p, dw, [&](const float (&spre)[NH]) {
+    // (sample indices are re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing to keep alive or spill)
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int n_e = lane_e & 15;
+    const bool q0_e = lane_e < 16;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int me = m0 + 16 * h + n_e;
+      if (me < a.M && q0_e) a.sigma[me] = fabsf(spre[h]);
+    }
+  }, cpre);
   const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int n_e = lane_e & 15;
   const bool q0_e = lane_e < 16;
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     const int me = m0 + 16 * h + n_e;
-    if (me < a.M && q0_e) a.sigma[me] = fabsf(spre[h]);
-  }
-  // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
-  bx_segment<S, NH, BXS_COL, 1, 4, 0, BXB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X), 7));
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    const int me = m0 + 16 * h + n_e;
     if (me < a.M && q0_e) {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) a.rgb[(size_t)me * 3 + ch] = 1.0f / (1.0f + expf(-acc[1].c[h][ch]));
+      for (int ch = 0; ch < 3; ++ch) a.rgb[(size_t)me * 3 + ch] = 1.0f / (1.0f + expf(-cpre[h][ch]));
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// SMALL batches (a rank's share of a strong-scaling step, the reference's 400-ray batch): the whole inference forward of TWO rays in one
+// workgroup and ONE launch -- coarse field pass (2 x 64 samples: 8 waves x 16), coarse composite + inverse-CDF resampling (two waves,
+// one ray each, ray_parts.h), fine field pass (2 x 128 samples: 8 waves x 32), merge + five channel sorts + composite (two waves).
+// As separate launches (field, k_coarse, field, k_merge) a 512-ray forward spends a third of its 0.12 ms in launch boundaries, cold
+// starts and a coarse pass that fills half of the chip's waves; here every CU renders a ray pair end to end, the weight image streams
+// through its LDS ring twice, and nothing but the ray records comes from -- and nothing but the two colours has to go to -- HBM (the
+// per-sample outputs are still written: they are the workspace's introspection buffers, 7.7 KB per pair).
+// Same arithmetic as the separate kernels: bx_field_pass is k_field_fwd_bf16x's body, the ray stages are ray_parts.h's functions --
+// the pixels are bit-identical (tests/test_gpu_bf16.py::test_pair_kernel_equals_separate_launches).  Needs Nc = 64, Nf = 128.
+// LDS: bias block [0, 16 KiB) whose tail behind the 70 bias tiles holds the pair's per-sample results, ring, parked encodings.
+// ------------------------------------------------------------------------------------------
+struct BxStreamNoBias : BxStream {
+  static constexpr bool HAS_BIAS = false;  // second pass: the bias block is in LDS already (and its tail holds the first pass's results)
+};
+constexpr int PAIR_NC = 64, PAIR_NF = 128;
+constexpr int PR_SIGC = 72 * 32;             // float offsets inside the bias block (tiles 0..69 are biases)
+constexpr int PR_RGBC = PR_SIGC + 2 * PAIR_NC;
+constexpr int PR_TF = PR_RGBC + 6 * PAIR_NC;
+constexpr int PR_SIGF = PR_TF + 2 * PAIR_NF;
+constexpr int PR_RGBF = PR_SIGF + 2 * PAIR_NF;
+static_assert((PR_RGBF + 6 * PAIR_NF) * 4 <= BF_BIAS_BYTES && PR_SIGC >= 32 * BF_NBIAS_TILES, "results live behind the bias tiles");
+
+__device__ __forceinline__ void wave_lds_fence() {  // this wave's LDS writes are visible to its own later reads (no workgroup barrier)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The two field passes of the pair kernel.  The second one gets its lane id, LDS base and offsets through opaque values (fresh_ctx): left
+// to itself the compiler shares address arithmetic between the two unrolled streams, keeps it alive across the first one, and the second
+// pass -- which fills the 256 registers of a wave on its own -- spills 230 of them.
+__device__ __forceinline__ BfCtx fresh_ctx(const BfCtx& c, unsigned char*& lds) {
+  unsigned zero = 0;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+  BfCtx d;
+  d.wimg = c.wimg;
+  d.lds = lds + zero;
+  d.lds_base = c.lds_base + zero;
+  d.lane = (int)lane_id_here();
+  d.wv = c.wv;
+  lds = d.lds;
+  return d;
+}
+__device__ __forceinline__ void pair_coarse_pass(const PairArgs& a, const BfCtx& c, unsigned char* lds, const int r0) {
+  float* const res = reinterpret_cast<float*>(lds);
+  // ================= coarse pass: sample s = 16 wv + n of the pair's 128 (ray s >> 6, depth index s & 63)
+  {
+    const int n = c.lane & 15;
+    const int s = 16 * c.wv + n, rl = s >> 6, i = s & 63;
+    const int ray = min(r0 + rl, a.B - 1);
+    const float* rf = a.rayf + (size_t)ray * RAYF;
+    float p[1][3], dw[1][3];
+    sample_point(rf, a.t_c[(size_t)ray * PAIR_NC + i], p[0]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dw[0][k] = rf[RF_DWRD + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(p[0][k]), "+v"(dw[0][k]));
+    float cpre[1][3];
+    bx_field_pass<BxStream, 1>(c, lds, p, dw, [&](const float (&spre)[1]) {
+      const int le = (int)lane_id_here();
+      if (le < 16) res[PR_SIGC + 16 * c.wv + le] = fabsf(spre[0]);
+    }, cpre);
+    const int le = (int)lane_id_here();
+    if (le < 16) {
+      const int se = 16 * c.wv + le;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) res[PR_RGBC + 3 * se + ch] = 1.0f / (1.0f + expf(-cpre[0][ch]));
+    }
+  }
+}
+
+__device__ __forceinline__ void pair_fine_pass(const PairArgs& a, const BfCtx& c, unsigned char* lds, const int r0) {
+  float* const res = reinterpret_cast<float*>(lds);
+  // ================= fine pass: sample s = 32 wv + 16 h + n of the pair's 256 (ray s >> 7, depth index s & 127)
+  {
+    const int n = c.lane & 15;
+    float p[2][3], dw[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int s = 32 * c.wv + 16 * h + n, rl = s >> 7;
+      const int ray = min(r0 + rl, a.B - 1);
+      const float* rf = a.rayf + (size_t)ray * RAYF;
+      sample_point(rf, res[PR_TF + s], p[h]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dw[h][k] = rf[RF_DWRD + k];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(p[h][k]), "+v"(dw[h][k]));
+    float cpre[2][3];
+    bx_field_pass<BxStreamNoBias, 2>(c, lds, p, dw, [&](const float (&spre)[2]) {
+      const int le = (int)lane_id_here();
+      if (le < 16) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) res[PR_SIGF + 32 * c.wv + 16 * h + le] = fabsf(spre[h]);
+      }
+    }, cpre);
+    const int le = (int)lane_id_here();
+    if (le < 16) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int se = 32 * c.wv + 16 * h + le;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) res[PR_RGBF + 3 * se + ch] = 1.0f / (1.0f + expf(-cpre[h][ch]));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(BF_WG, 1) void k_render_pair_bf16x(const PairArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  BfCtx c;
+  c.wimg = a.wbf;
+  c.lds = lds;
+  c.lds_base = (unsigned)(uintptr_t)(lptr_t)lds;
+  c.lane = threadIdx.x & 63;
+  c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* const res = reinterpret_cast<float*>(lds);
+  const int r0 = 2 * blockIdx.x;  // this workgroup's rays r0, r0 + 1 (the second one may lie behind the batch: computed on a copy, not stored)
+
+  pair_coarse_pass(a, c, lds, r0);
+  __syncthreads();  // the pair's coarse sigma / rgb are in LDS; nobody reads the ring any more
+  // ================= coarse composite + resampling: waves 0, 1 take one ray each; the ring's first bytes are their scratch
+  if (c.wv < 2) {
+    const int lane = (int)lane_id_here();
+    const int rl = c.wv, ray_raw = r0 + rl;
+    const bool live = ray_raw < a.B;
+    const int ray = live ? ray_raw : a.B - 1;
+    const float* rf = a.rayf + (size_t)ray * RAYF;
+    const float near = rf[RF_NEAR], far = rf[RF_FAR];
+    const float n0 = a.ray0_override ? a.near0 : a.rayf[RF_NEAR], f0 = a.ray0_override ? a.far0 : a.rayf[RF_FAR];
+    const float delta0 = ray0_spacing(n0, f0, PAIR_NC);
+    float* scr = reinterpret_cast<float*>(lds + BF_BIAS_BYTES) + rl * 3 * PAIR_NC;
+    float* sw = scr, *scdf = scr + PAIR_NC, *stc = scr + 2 * PAIR_NC;
+    const size_t g0 = (size_t)ray * PAIR_NC;
+    float lo, hi;
+    coarse_ray_weights(res + PR_SIGC + PAIR_NC * rl, res + PR_RGBC + 3 * PAIR_NC * rl, a.t_c + g0, near, far, PAIR_NC, lane, sw, scdf, stc,
+                       (live && a.w_c) ? a.w_c + g0 : nullptr, live ? a.C_coarse + (size_t)ray * 3 : nullptr, lo, hi);
+    wave_lds_fence();
+    const bool bad = coarse_ray_resample(sw, scdf, stc, lo, hi, delta0, PAIR_NC, PAIR_NF, lane, res + PR_TF + PAIR_NF * rl);
+    if (live && bad && a.status) atomicOr(a.status, 1u);
+    if (live && bad && a.sticky) atomicOr(a.sticky, 1u);
+    wave_lds_fence();
+    if (live) {  // the workspace's per-sample buffers of the coarse pass and the fine depths (introspection; 2.5 KB per ray)
+      if (a.sig_c) a.sig_c[g0 + lane] = res[PR_SIGC + PAIR_NC * rl + lane];
+      if (a.rgb_c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.rgb_c[g0 * 3 + 64 * k + lane] = res[PR_RGBC + 3 * PAIR_NC * rl + 64 * k + lane];
+      if (a.t_f)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) a.t_f[(size_t)ray * PAIR_NF + 64 * k + lane] = res[PR_TF + PAIR_NF * rl + 64 * k + lane];
+    }
+  }
+  __syncthreads();  // the fine depths are in LDS; the scratch in the ring is free
+  {
+    unsigned char* lds2 = lds;
+    const BfCtx c2 = fresh_ctx(c, lds2);
+    pair_fine_pass(a, c2, lds2, r0);
+  }
+  __syncthreads();  // the pair's fine sigma / rgb are in LDS; the ring is free
+  // ================= merge + five channel sorts + composite (nerf.py:302-321): waves 0, 1, one ray each, val [5][256] in the ring
+  if (c.wv < 2) {
+    const int lane = (int)lane_id_here();
+    const int rl = c.wv, ray_raw = r0 + rl;
+    const bool live = ray_raw < a.B;
+    const int ray = live ? ray_raw : a.B - 1;
+    constexpr int P = 256, N = PAIR_NC + PAIR_NF;
+    float* val = reinterpret_cast<float*>(lds + BF_BIAS_BYTES) + rl * 5 * P;
+    const size_t g0 = (size_t)ray * PAIR_NC;
+    for (int i = lane; i < P; i += 64) {  // channel 0 = t, 1..3 = rgb, 4 = sigma (k_merge's load, from LDS)
+      float v[5];
+      if (i < PAIR_NC) {
+        v[0] = a.t_c[g0 + i];
+        v[1] = res[PR_RGBC + 3 * (PAIR_NC * rl + i)]; v[2] = res[PR_RGBC + 3 * (PAIR_NC * rl + i) + 1]; v[3] = res[PR_RGBC + 3 * (PAIR_NC * rl + i) + 2];
+        v[4] = res[PR_SIGC + PAIR_NC * rl + i];
+      } else if (i < N) {
+        const int j = PAIR_NF * rl + (i - PAIR_NC);
+        v[0] = res[PR_TF + j];
+        v[1] = res[PR_RGBF + 3 * j]; v[2] = res[PR_RGBF + 3 * j + 1]; v[3] = res[PR_RGBF + 3 * j + 2];
+        v[4] = res[PR_SIGF + j];
+      } else {
+        v[0] = v[1] = v[2] = v[3] = v[4] = __builtin_nanf("");
+      }
+#pragma unroll
+      for (int ch = 0; ch < 5; ++ch) val[ch * P + i] = v[ch];
+    }
+    if (live) {  // the workspace's per-sample buffers of the fine pass (introspection)
+      const size_t gf = (size_t)ray * PAIR_NF;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (a.sig_f) a.sig_f[gf + 64 * k + lane] = res[PR_SIGF + PAIR_NF * rl + 64 * k + lane];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (a.rgb_f) a.rgb_f[gf * 3 + 64 * k + lane] = res[PR_RGBF + 3 * PAIR_NF * rl + 64 * k + lane];
+    }
+    wave_lds_fence();
+    float cf[3];
+    float* const cout = live ? a.C_fine + (size_t)ray * 3 : cf;  // (a dead second ray: composited into registers nobody reads)
+    merge_ray_sort_composite<false>(val, nullptr, P, N, a.last, lane, nullptr, nullptr, nullptr, cout, [] { wave_lds_fence(); });
+  }
+}
+
+hipError_t launch_render_pair_bf16x(const PairArgs& a, hipStream_t st) {
+  static std::atomic<unsigned long long> opted{0};
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_render_pair_bf16x)}, BX_LDS_BYTES)) return e;
+  hipLaunchKernelGGL(k_render_pair_bf16x, dim3((a.B + 1) / 2), dim3(BF_WG), BX_LDS_BYTES, st, a);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -114,6 +114,22 @@ hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_pack_weights_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 hipError_t launch_pack_bias_block_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st);  // inference, 16x16x32 MFMA form
+// small batches, Nc = 64 / Nf = 128: the whole inference forward of a ray PAIR per workgroup in one launch (field_fwd_bf16x.hip)
+struct PairArgs {
+  const unsigned char* wbf;   // 16x16x32 weight image
+  const float* rayf;          // [B][RAYF]
+  const float* t_c;           // [B][64]
+  int B;
+  int ray0_override;          // quirk Q6: 1 = near0 / far0 below are the batch's GLOBAL ray 0's, 0 = this call's ray 0
+  float near0, far0;
+  float last;                 // nerf.py:286
+  float* C_coarse;            // [B][3]
+  float* C_fine;              // [B][3]
+  uint32_t* status;
+  uint32_t* sticky;
+  float *sig_c, *rgb_c, *w_c, *t_f, *sig_f, *rgb_f;  // the workspace's per-sample buffers (written for introspection; may be null)
+};
+hipError_t launch_render_pair_bf16x(const PairArgs& a, hipStream_t st);
 hipError_t launch_pack_weights_bf16x(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 // split-fp32 inference (field_fwd_split.hip): fp32 operands as two bf16 parts, three bf16 MFMAs per product
 size_t split_image_bytes();
@@ -121,10 +137,11 @@ hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsi
 hipError_t launch_field_fwd_split(const FieldArgs& a, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
 // bf16 paths: fold + packed image(s) + ray records in ONE launch (prep_bf16.hip).  img_fwd: forward image (fwd_form 0: 32x32x16 stream,
-// 1: 16x16x32) or null = weights unchanged; img_bwd: transposed image of the backward chain or null; sync: an 8-byte word of the workspace
-// that no other kernel writes; token: unique per call, never 0; sticky: the sticky status word (timeout report) or null
+// 1: 16x16x32) or null = weights unchanged; img_bwd: transposed image of the backward chain or null; ready: PREP_READY_WORDS u32 words of the
+// workspace that no other kernel writes; token: unique per call; sticky: the sticky status word (timeout report) or null
+constexpr int PREP_READY_WORDS = 256;
 hipError_t launch_prep_bf16(const Weights24& w, float* fold, unsigned char* img_fwd, int fwd_form, unsigned char* img_bwd,
-                            unsigned long long* sync, unsigned token, unsigned* sticky, const RaysArgs& rays, hipStream_t st);
+                            unsigned* ready, unsigned token, unsigned* sticky, const RaysArgs& rays, hipStream_t st);
 hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st);
 size_t merge_lds_bytes(int P);
 hipError_t launch_merge(const MergeArgs& a, hipStream_t st);

@@ -7,11 +7,12 @@
 // each -- 21-28 us of a 512-ray step that takes 143 / 740 us (forward / train step).  The only dependency among them is fold -> the
 // 37 blocks that pack folded fragments (dir_info's h7 columns, forward and transposed, and the bias tiles that carry b_fold); those blocks
 // wait for the fold blocks INSIDE the launch:
-//   * every fold block, after its stores have drained (all threads: s_waitcnt vmcnt(0); barrier) releases at agent scope and bumps ONE
-//     64-bit word {token, count} (token = this call's id, handed in by the host: a word left over from an earlier call -- or never
-//     initialised -- cannot be mistaken for this call's, so nothing has to be zeroed between calls);
-//   * a packing block that needs the fold polls that word with ONE lane (relaxed, agent scope) until it reads {token, 129}, acquires at
-//     agent scope (this CU's L1 may hold stale lines of the fold scratch from the previous call) and goes through a barrier.
+//   * every fold block, after its stores have drained (all threads: s_waitcnt vmcnt(0); barrier) releases at agent scope and stores this
+//     call's TOKEN (handed in by the host, unique per call) into its own word of a 129-word array: a word left over from an earlier
+//     call -- or never initialised -- cannot be mistaken for this call's, so nothing has to be zeroed between calls, and nobody does a
+//     read-modify-write;
+//   * a packing block that needs the fold polls the 129 words with 129 threads (relaxed, agent scope), goes through a barrier, ONE lane
+//     acquires at agent scope (this CU's L1 may hold stale lines of the fold scratch from the previous call), barrier.
 // No deadlock: fold blocks wait for nothing, they are the lowest block indices of the grid (dispatched first on every XCD), and the
 // poll is BOUNDED: after PREP_SPIN_LIMIT polls the block gives up, sets NERF_HIP_STATUS_PREP_TIMEOUT in the sticky status word and packs
 // what it finds (wrong numbers, reported -- never a hang).
@@ -34,39 +35,38 @@ struct PrepArgs {
   unsigned char* img_fwd;      // forward image (bias block + stream) or null
   int fwd_form;                // 0: 32x32x16 (training / FORCE_TILE), 1: 16x16x32 (inference)
   unsigned char* img_bwd;      // transposed image or null
-  unsigned long long* sync;    // {token << 32 | fold blocks done}
+  unsigned* ready;             // [PREP_FOLD_BLOCKS]: fold block o stores this call's token into ready[o] when its row is out
   unsigned token;
   unsigned* sticky;            // status word that no kernel clears
   RaysArgs rays;               // rays.B = 0: no ray part
   int b_fwd0, b_bwd0, b_bias0, b_rays0, b_end;  // first block of every part (fold blocks first)
 };
 
-__device__ __forceinline__ void prep_publish_fold(const PrepArgs& a) {
+__device__ __forceinline__ void prep_publish_fold(const PrepArgs& a, const int block) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long mine = (unsigned long long)a.token << 32;
-    unsigned long long cur = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {  // {token, n} -> {token, n + 1}; anything else (an older call's word, garbage) -> {token, 1}
-      const unsigned long long want = ((cur >> 32) == a.token) ? cur + 1 : (mine | 1ull);
-      if (__hip_atomic_compare_exchange_strong(a.sync, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
+    // one word per fold block, no read-modify-write: 129 blocks bumping ONE counter by compare-and-swap (the first version) serialised
+    // into 0.2 ms of retries
+    __hip_atomic_store(a.ready + block, a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 __device__ __forceinline__ void prep_wait_fold(const PrepArgs& a) {
-  if (threadIdx.x == 0) {
-    const unsigned long long done = ((unsigned long long)a.token << 32) | (unsigned)PREP_FOLD_BLOCKS;
+  if (threadIdx.x < PREP_FOLD_BLOCKS) {  // thread t polls fold block t's word (relaxed, agent scope: an sc1 load, never this CU's L1)
     unsigned spins = 0;
-    while (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != done) {
+    while (__hip_atomic_load(a.ready + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.token) {
       if (++spins >= PREP_SPIN_LIMIT) {
         if (a.sticky) atomicOr(a.sticky, 2u);  // NERF_HIP_STATUS_PREP_TIMEOUT
         break;
       }
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(4);
     }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_prep_bf16(const PrepArgs a) {
   const int b = blockIdx.x;
   if (b < a.b_fwd0) {  // (no fold blocks when nothing is packed: b_fwd0 = 0)
     fold_block(a.w, a.fold, b);
-    prep_publish_fold(a);
+    prep_publish_fold(a, b);
     return;
   }
   if (b < a.b_bwd0) {  // forward stream: 4 fragments per block
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(256) void k_prep_bf16(const PrepArgs a) {
 
 // img_fwd: forward image of the chosen form (or null: weights unchanged); img_bwd: transposed image or null; rays.B = 0: no ray part
 hipError_t launch_prep_bf16(const Weights24& w, float* fold, unsigned char* img_fwd, int fwd_form, unsigned char* img_bwd,
-                            unsigned long long* sync, unsigned token, unsigned* sticky, const RaysArgs& rays, hipStream_t st) {
+                            unsigned* ready, unsigned token, unsigned* sticky, const RaysArgs& rays, hipStream_t st) {
   if (rays.dvec) return hipErrorInvalidValue;  // (the fp32 path's per-ray start vector needs b_fold: it keeps k_rays)
   PrepArgs a;
-  a.w = w; a.fold = fold; a.img_fwd = img_fwd; a.fwd_form = fwd_form; a.img_bwd = img_bwd; a.sync = sync; a.token = token; a.sticky = sticky;
+  a.w = w; a.fold = fold; a.img_fwd = img_fwd; a.fwd_form = fwd_form; a.img_bwd = img_bwd; a.ready = ready; a.token = token; a.sticky = sticky;
   a.rays = rays;
   int b = (img_fwd || img_bwd) ? PREP_FOLD_BLOCKS : 0;
   a.b_fwd0 = b; b += img_fwd ? (fwd_form == 0 ? PF_BLOCKS : PX_BLOCKS) : 0;

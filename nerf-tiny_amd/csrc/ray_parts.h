@@ -1,0 +1,302 @@
+// ray_parts.h -- the per-ray stages of the hot path as device functions of ONE 64-lane wave: coarse weights + C_coarse, inverse-CDF
+// resampling, the five channel sorts and the merged composite.  Used by their stand-alone kernels (k_coarse, k_merge: ray_ops.hip) and by the
+// fused small-batch kernel that renders a pair of rays in one workgroup (field_pair_bf16x.hip) -- one source, the same bits.
+// None of these functions contains a workgroup barrier: callers whose workgroup is one wave per ray pass __syncthreads() as `sync`, callers
+// that run them on SOME waves of a bigger workgroup pass a wave-level fence.  MI355X / gfx950 only; built with -ffp-contract=off.
+#pragma once
+#include "kernels.h"
+
+namespace nerf {
+
+constexpr int MAXN = 1024;
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  return v;
+}
+
+
+// coarse spacing of ray 0 as the reference takes it (quirk Q6, nerf.py:233): t[0][1] - t[0][0] of numpy.linspace(near, far, Nc)
+__device__ __forceinline__ float ray0_spacing(float n0, float f0, int Nc) {
+  const float st0 = (f0 - n0) / (float)(Nc - 1);
+  const float t1 = (Nc == 2) ? f0 : (1.0f * st0 + n0);
+  return t1 - n0;
+}
+
+// get_density (nerf.py:263-272) with delta = (far - near) / Nc (quirk Q5), color_cum (nerf.py:274-281): the ray's Nc coarse samples at
+// sigma[i], rgb[3 i + ch], t_c[i] (global or LDS) -> w, cdf, tc (LDS, this wave's), optionally w_c (global) and C_coarse[3]; lo / hi =
+// min / max of the cdf (nerf.py:240-241).  The caller orders the LDS writes before coarse_ray_resample's reads.
+__device__ __forceinline__ void coarse_ray_weights(const float* sigma, const float* rgb, const float* t_c, float near, float far, int Nc, int lane,
+                                                   float* w, float* cdf, float* tc, float* w_c_out, float* C_out, float& lo_out, float& hi_out) {
+  const float delta_c = (far - near) / (float)Nc;
+  double carry = 0.0, carry2 = 0.0;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int base = 0; base < Nc; base += 64) {
+    const int i = base + lane;
+    const bool v = i < Nc;
+    const int gi = v ? i : 0;
+    const float sg = v ? sigma[gi] : 0.f;
+    const float s = delta_c * sg;
+    double cs = wave_incl_scan((double)s, lane) + carry;
+    carry = __shfl(cs, 63);
+    const float T = expf(-(float)cs);
+    const float wi = v ? T * (1.0f - expf(-s)) : 0.f;
+    double cw = wave_incl_scan((double)wi, lane) + carry2;
+    carry2 = __shfl(cw, 63);
+    const float cd = (float)cw;
+    if (v) {
+      w[i] = wi;
+      cdf[i] = cd;
+      tc[i] = t_c[gi];
+      if (w_c_out) w_c_out[gi] = wi;
+      c0 += wi * rgb[gi * 3 + 0];
+      c1 += wi * rgb[gi * 3 + 1];
+      c2 += wi * rgb[gi * 3 + 2];
+      lo = fminf(lo, cd);
+      hi = fmaxf(hi, cd);
+    }
+  }
+  c0 = wave_sum(c0);
+  c1 = wave_sum(c1);
+  c2 = wave_sum(c2);
+  lo_out = wave_min(lo);
+  hi_out = wave_max(hi);
+  if (lane == 0 && C_out) {
+    C_out[0] = c0;
+    C_out[1] = c1;
+    C_out[2] = c2;
+  }
+}
+
+// resample (nerf.py:225-261): u_j = lo + j * ((hi - lo)/(Nf+1)), j = 1..Nf (numpy.linspace(lo, hi, Nf+2)[1:-1] in fp32, nerf.py:243-246),
+// searchsorted (left) in the cdf, t_f = t_c[k] + (u - cdf[k]) * delta0 / (w[k+1] + 1e-7).  Returns whether any lane met the condition of
+// nerf.py:251 (quirk Q7: the index is clamped here, the caller reports).  t_f_out: Nf floats (global or LDS) or null.
+__device__ __forceinline__ bool coarse_ray_resample(const float* w, const float* cdf, const float* tc, float lo, float hi, float delta0, int Nc, int Nf,
+                                                    int lane, float* t_f_out) {
+  const float step = (hi - lo) / (float)(Nf + 1);
+  bool bad = false;
+  for (int j = lane; j < Nf; j += 64) {
+    const float u = (float)(j + 1) * step + lo;
+    // searchsorted(cdf, u) (left) = number of cdf entries < u
+    int lo_i = 0, hi_i = Nc;
+    while (lo_i < hi_i) {
+      const int mid = (lo_i + hi_i) >> 1;
+      if (cdf[mid] < u) lo_i = mid + 1; else hi_i = mid;
+    }
+    int k = lo_i - 1;
+    if (k > Nf - 1 || k < 0) bad = true;  // the condition of nerf.py:251 (quirk Q7)
+    k = k < 0 ? 0 : (k > Nc - 1 ? Nc - 1 : k);
+    const float slope = (k + 1 < Nc) ? delta0 / (w[k + 1] + 1e-7f) : 0.f;
+    const float tf = tc[k] + (u - cdf[k]) * slope;
+    if (t_f_out) t_f_out[j] = tf;
+  }
+  return bad;
+}
+
+// Bitonic sort of five independent 256-slot channels by one wave IN REGISTERS: lane l holds slots 4l .. 4l+3 of every channel, so
+// the 15 stages with partner distance 1 or 2 are lane-local and the 21 others exchange with lane l ^ (distance / 4) through DPP
+// (distance 4, 8), ds_swizzle (16 .. 64) or one permute (128) -- no LDS traffic between stages and no barriers (the LDS version
+// spent 36 barriers and ~500 two-address LDS instructions per ray).  Keys are the floats' order-preserving unsigned images
+// (sign flipped for positives, all bits for negatives; -0 keyed as +0 and NaN as the maximum: the order of torch.sort); WITH_IDX carries
+// the original slot as the low half of a 64-bit key, which makes the order total (= a stable sort, as before).
+template <int D>
+__device__ __forceinline__ unsigned lane_xor_get(unsigned v) {  // v of lane (l ^ D)
+  if constexpr (D == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  else if constexpr (D < 32) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (D << 10));   // bit-mask mode: xor D inside 32 lanes
+  else return (unsigned)__shfl_xor((int)v, 32);
+}
+// torch.sort's order: -0 and +0 compare equal (both map to +0's key; the original index breaks the tie, as everywhere), every NaN
+// sorts last (the maximum key, above the +inf padding).
+__device__ __forceinline__ unsigned sort_key(float x) {
+  unsigned b = __float_as_uint(x);
+  if ((b & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;  // NaN of either sign
+  if (b == 0x80000000u) b = 0u;                              // -0 -> +0
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float sort_unkey(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+
+template <bool WITH_IDX, int K, int J>
+__device__ __forceinline__ void sortreg_stage(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
+  if constexpr (J >= 4) {
+    constexpr int D = J / 4;
+    const bool upper = (lane & D) != 0;
+    const bool asc = K >= 256 ? true : ((4 * lane) & K) == 0;
+    const bool flip = upper != !asc;  // take the partner's element iff (mine > partner's) != flip
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned pk = lane_xor_get<D>(key[c][r]);
+        bool gt;
+        unsigned pi = 0;
+        if (WITH_IDX) {
+          pi = lane_xor_get<D>(ix[c][r]);
+          gt = (((unsigned long long)key[c][r] << 32) | ix[c][r]) > (((unsigned long long)pk << 32) | pi);
+        } else {
+          gt = key[c][r] > pk;
+        }
+        const bool take = gt != flip;
+        key[c][r] = take ? pk : key[c][r];
+        if (WITH_IDX) ix[c][r] = take ? pi : ix[c][r];
+      }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r & J) continue;
+        const int q = r | J;
+        const bool asc = K >= 256 ? true : ((4 * lane + r) & K) == 0;
+        const unsigned a = key[c][r], bb = key[c][q];
+        bool gt;
+        if (WITH_IDX) gt = (((unsigned long long)a << 32) | ix[c][r]) > (((unsigned long long)bb << 32) | ix[c][q]);
+        else gt = a > bb;
+        const bool sw = gt == asc;
+        key[c][r] = sw ? bb : a;
+        key[c][q] = sw ? a : bb;
+        if (WITH_IDX) {
+          const unsigned ia = ix[c][r], ib = ix[c][q];
+          ix[c][r] = sw ? ib : ia;
+          ix[c][q] = sw ? ia : ib;
+        }
+      }
+  }
+}
+template <bool WITH_IDX, int K, int J>
+__device__ __forceinline__ void sortreg_merge(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
+  sortreg_stage<WITH_IDX, K, J>(key, ix, lane);
+  if constexpr (J > 1) sortreg_merge<WITH_IDX, K, J / 2>(key, ix, lane);
+}
+template <bool WITH_IDX, int K>
+__device__ __forceinline__ void sortreg_from(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
+  sortreg_merge<WITH_IDX, K, K / 2>(key, ix, lane);
+  if constexpr (K < 256) sortreg_from<WITH_IDX, K * 2>(key, ix, lane);
+}
+// val [5][256] floats (and idx [5][256] u16, WITH_IDX) in LDS: read as 4 slots per lane, sort, write back in sorted order
+template <bool WITH_IDX, class Sync>
+__device__ __forceinline__ void sort256_regs(float* val, uint16_t* idx, int lane, Sync&& sync) {
+  unsigned key[5][4], ix[5][4];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(val + c * 256 + 4 * lane);
+    key[c][0] = sort_key(v.x); key[c][1] = sort_key(v.y); key[c][2] = sort_key(v.z); key[c][3] = sort_key(v.w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ix[c][r] = (unsigned)(4 * lane + r);  // (= what the loader wrote to idx)
+  }
+  sortreg_from<WITH_IDX, 2>(key, ix, lane);
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    *reinterpret_cast<float4*>(val + c * 256 + 4 * lane) =
+        make_float4(sort_unkey(key[c][0]), sort_unkey(key[c][1]), sort_unkey(key[c][2]), sort_unkey(key[c][3]));
+    if (WITH_IDX) {
+      uint2 pk;
+      pk.x = ix[c][0] | (ix[c][1] << 16);
+      pk.y = ix[c][2] | (ix[c][3] << 16);
+      *reinterpret_cast<uint2*>(idx + c * 256 + 4 * lane) = pk;
+    }
+  }
+  sync();
+}
+
+
+// nerf.py:302-321 behind the load: val [5][P] (channel 0 = t, 1..3 = rgb, 4 = sigma; slots >= N padded with NaN) and, WITH_IDX, idx [5][P]
+// = the original slot, in LDS -> five independent ascending channel sorts (quirk Q1), delta_i = t_{i+1} - t_i with the last = `last`,
+// weights, C_fine[3]; optionally w [N], the sorted bundle [N][5] and the permutations perm [5][N] (global).
+template <bool WITH_IDX, class Sync>
+__device__ __forceinline__ void merge_ray_sort_composite(float* val, uint16_t* idx, int P, int N, float last, int lane, float* w_out, float* bundle_out,
+                                                         uint16_t* perm_out, float* C_out, Sync&& sync) {
+  if (P == 256) {  // the usual size (64 + 128 samples): the whole network in registers
+    sort256_regs<WITH_IDX>(val, idx, lane, sync);
+  } else
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int tI = lane; tI < (P >> 1); tI += 64) {
+        const int i = ((tI & ~(j - 1)) << 1) | (tI & (j - 1));  // element with bit j clear
+        const int l = i | j;
+        const bool asc = (i & k) == 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const float x = val[c * P + i], y = val[c * P + l];
+          if (WITH_IDX) {
+            const uint16_t xi = idx[c * P + i], yi = idx[c * P + l];
+            const unsigned kx = sort_key(x), ky = sort_key(y);  // the register network's order: +-0 equal, NaN last
+            const bool gt = (kx > ky) || (kx == ky && xi > yi);
+            if (gt == asc) {
+              val[c * P + i] = y; val[c * P + l] = x;
+              idx[c * P + i] = yi; idx[c * P + l] = xi;
+            }
+          } else {  // values only: equal keys are interchangeable
+            const unsigned kx = sort_key(x), ky = sort_key(y);
+            const bool gt = kx > ky;
+            if (gt == asc && kx != ky) {
+              val[c * P + i] = y; val[c * P + l] = x;
+            }
+          }
+        }
+      }
+      sync();
+    }
+  }
+  // composite over the sorted channels
+  double carry = 0.0;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int base = 0; base < N; base += 64) {
+    const int i = base + lane;
+    const bool v = i < N;
+    const float ti = v ? val[i] : 0.f;
+    const float dl = (v && i + 1 < N) ? (val[i + 1] - ti) : last;
+    const float sg = v ? val[4 * P + i] : 0.f;
+    const float s = v ? dl * sg : 0.f;
+    double cs = wave_incl_scan((double)s, lane) + carry;
+    carry = __shfl(cs, 63);
+    const float T = expf(-(float)cs);
+    const float wi = v ? T * (1.0f - expf(-s)) : 0.f;
+    if (v) {
+      const float r = val[P + i], g = val[2 * P + i], b = val[3 * P + i];
+      c0 += wi * r; c1 += wi * g; c2 += wi * b;
+      if (w_out) w_out[i] = wi;
+      if (bundle_out) {
+        float* o = bundle_out + (size_t)i * 5;
+        o[0] = ti; o[1] = r; o[2] = g; o[3] = b; o[4] = sg;
+      }
+      if (WITH_IDX && perm_out) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) perm_out[(size_t)c * N + i] = idx[c * P + i];
+      }
+    }
+  }
+  c0 = wave_sum(c0);
+  c1 = wave_sum(c1);
+  c2 = wave_sum(c2);
+  if (lane == 0) {
+    C_out[0] = c0;
+    C_out[1] = c1;
+    C_out[2] = c2;
+  }
+}
+
+}  // namespace nerf

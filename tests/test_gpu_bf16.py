@@ -378,7 +378,7 @@ def _variant(tmp_path, name, env_extra, B=96):
 
     from conftest import ROOT
 
-    env = {k: v for k, v in os.environ.items() if k not in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI")}
+    env = {k: v for k, v in os.environ.items() if k not in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16")}
     env.update(env_extra)
     out = str(tmp_path / (name + ".pt"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "bf16_variant_dump.py"), out, str(B)], capture_output=True, text=True,
@@ -397,7 +397,7 @@ def test_one_launch_preparation_equals_separate_launches(tmp_path):
     new = _variant(tmp_path, "prep1", {"NERF_DW_BF16_MULTI": "1"})
     old = _variant(tmp_path, "prep0", {"NERF_PREP_BF16": "0", "NERF_DW_BF16_MULTI": "1"})
     assert new["sticky"] == 0 and old["sticky"] == 0
-    for k in ("train_packed_bf", "infer_packed_bf", "rayf", "t_c", "Cc", "Cf", "Ic", "If", "Fc", "Ff"):
+    for k in ("train_packed_bf", "infer_packed_bf", "rayf", "t_c", "Cc", "Cf", "Ic", "If", "Fc", "Ff", "Sc", "Sf"):
         assert torch.equal(new[k], old[k]), k
     assert new["loss"] == old["loss"]
     for a, b in zip(new["grads"], old["grads"]):
@@ -417,3 +417,19 @@ def test_weight_gradients_in_one_launch_equal_a_launch_per_product(tmp_path):
         for i, (a, b) in enumerate(zip(one["grads"], per["grads"])):
             assert torch.isfinite(a).all()
             assert float((a.double() - b.double()).norm()) <= 1e-5 * float(b.double().norm()) + 1e-12, (B, i)
+
+
+@pytest.mark.timeout(900)
+def test_pair_kernel_equals_separate_launches(tmp_path):
+    """field_fwd_bf16x.hip k_render_pair_bf16x (small bf16-MLP inference batches, Nc = 64 / Nf = 128): both field passes, the coarse
+    composite + resampling and the merge + channel sorts + composite of a ray PAIR in one workgroup and ONE launch, against the four
+    separate launches (NERF_PAIR_BF16=0, a process of its own).  Same functions (bx_field_pass, ray_parts.h), so the same bits: the two
+    colours, every per-sample buffer of the workspace, the status word; an odd batch (the last workgroup holds ONE ray), a shard that is
+    handed the global ray 0's near / far, a ray that meets the reference's exit(0) condition."""
+    for B in (97, 256):
+        one = _variant(tmp_path, f"pair1_{B}", {"NERF_PAIR_BF16": "1"}, B)
+        sep = _variant(tmp_path, f"pair0_{B}", {"NERF_PAIR_BF16": "0"}, B)
+        for k in ("Ic", "If", "Fc", "Ff", "Sc", "Sf", "infer_sig_c", "infer_rgb_c", "infer_w_c", "infer_t_f", "infer_sig_f", "infer_rgb_f"):
+            assert torch.equal(one[k], sep[k]), (B, k)
+        assert one["S_fault"] is True and sep["S_fault"] is True
+        assert one["sticky"] & 2 == 0

@@ -57,6 +57,16 @@ def main():
     wsi = m.last_workspace
     res["infer_packed_bf"] = region("packed_bf", img_bytes, _abi.BF16_MLP, wsi)
     res["Ic"], res["If"] = Ic.cpu(), If.cpu()
+    for name, n in (("sig_c", B * Nc), ("rgb_c", B * Nc * 3), ("w_c", B * Nc), ("t_f", B * Nf), ("sig_f", B * Nf), ("rgb_f", B * Nf * 3)):
+        res["infer_" + name] = region(name, n * 4, _abi.BF16_MLP, wsi)  # the workspace's per-sample buffers of the inference call
+    # a shard that does not start at the batch's ray 0 (quirk Q6: the global ray 0's near / far handed in) and the status word
+    m.ray0_near_far = (float(pb[0, 15]) * 0.9, float(pb[0, 16]) * 1.1)
+    pb_bad = pb.clone()
+    pb_bad[B // 2, 16] = pb_bad[B // 2, 15]  # one ray with far = near: the reference's exit(0) condition
+    with torch.no_grad():
+        Sc, Sf = m(row, col, pb_bad, K)
+    res["Sc"], res["Sf"], res["S_fault"] = Sc.cpu(), Sf.cpu(), bool(m.resample_fault())
+    m.ray0_near_far = None
     # frozen rendering loop: the second call reuses the image and only makes the ray records
     with torch.no_grad(), m.frozen_weights():
         m(row, col, pb, K)
@@ -65,7 +75,7 @@ def main():
     st = C.c_uint32(0)
     _abi.check(_abi.lib().nerf_hip_read_status_sticky(ws.data_ptr(), ws.numel(), C.byref(st), 0, torch.cuda.current_stream(dev).cuda_stream))
     res["sticky"] = int(st.value)
-    res["env"] = {k: os.environ.get(k) for k in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI")}
+    res["env"] = {k: os.environ.get(k) for k in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16")}
     torch.save(res, out)
     print("DUMP-OK", res["env"], flush=True)
 
