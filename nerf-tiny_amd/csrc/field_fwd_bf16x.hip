@@ -288,6 +288,12 @@ __device__ __forceinline__ void wave_lds_fence() {  // this wave's LDS writes ar
   __builtin_amdgcn_wave_barrier();
 }
 
+// The lane id through the mbcnt BUILTINS (not bf16_stream.h's volatile asm): behind an MFMA the compiler may hand the asm a destination
+// register that overlaps the accumulator of an MFMA still in flight (a dead row of it) -- the hazard recognizer does not look inside the
+// asm, the MFMA's late write then clobbers the lane id (seen: every lane stored to sample 0).  With the builtins the wait states are
+// inserted.
+__device__ __forceinline__ int lane_id_builtin() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 // The two field passes of the pair kernel.  The second one gets its lane id, LDS base and offsets through opaque values (fresh_ctx): left
 // to itself the compiler shares address arithmetic between the two unrolled streams, keeps it alive across the first one, and the second
 // pass -- which fills the 256 registers of a wave on its own -- spills 230 of them.
@@ -319,10 +325,10 @@ __device__ __forceinline__ void pair_coarse_pass(const PairArgs& a, const BfCtx&
     for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(p[0][k]), "+v"(dw[0][k]));
     float cpre[1][3];
     bx_field_pass<BxStream, 1>(c, lds, p, dw, [&](const float (&spre)[1]) {
-      const int le = (int)lane_id_here();
+      const int le = lane_id_builtin();
       if (le < 16) res[PR_SIGC + 16 * c.wv + le] = fabsf(spre[0]);
     }, cpre);
-    const int le = (int)lane_id_here();
+    const int le = lane_id_builtin();
     if (le < 16) {
       const int se = 16 * c.wv + le;
 #pragma unroll
@@ -352,13 +358,13 @@ __device__ __forceinline__ void pair_fine_pass(const PairArgs& a, const BfCtx& c
       for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(p[h][k]), "+v"(dw[h][k]));
     float cpre[2][3];
     bx_field_pass<BxStreamNoBias, 2>(c, lds, p, dw, [&](const float (&spre)[2]) {
-      const int le = (int)lane_id_here();
+      const int le = lane_id_builtin();
       if (le < 16) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) res[PR_SIGF + 32 * c.wv + 16 * h + le] = fabsf(spre[h]);
       }
     }, cpre);
-    const int le = (int)lane_id_here();
+    const int le = lane_id_builtin();
     if (le < 16) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_render_pair_bf16x(const PairArgs a
   __syncthreads();  // the pair's coarse sigma / rgb are in LDS; nobody reads the ring any more
   // ================= coarse composite + resampling: waves 0, 1 take one ray each; the ring's first bytes are their scratch
   if (c.wv < 2) {
-    const int lane = (int)lane_id_here();
+    const int lane = lane_id_builtin();
     const int rl = c.wv, ray_raw = r0 + rl;
     const bool live = ray_raw < a.B;
     const int ray = live ? ray_raw : a.B - 1;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_render_pair_bf16x(const PairArgs a
   __syncthreads();  // the pair's fine sigma / rgb are in LDS; the ring is free
   // ================= merge + five channel sorts + composite (nerf.py:302-321): waves 0, 1, one ray each, val [5][256] in the ring
   if (c.wv < 2) {
-    const int lane = (int)lane_id_here();
+    const int lane = lane_id_builtin();
     const int rl = c.wv, ray_raw = r0 + rl;
     const bool live = ray_raw < a.B;
     const int ray = live ? ray_raw : a.B - 1;
