@@ -303,6 +303,9 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   // bf16-MLP calls: fold, packed image(s) -- a training call's transposed image for the backward chain included -- and the ray records
   // in ONE launch (prep_bf16.hip) instead of three or four dependent ones
   const bool one_prep = bf16 && !split && !prep_bf16_disabled();
+  // SMALL bf16-MLP inference batches at the shipped sample counts: ONE launch renders every ray pair end to end, ray records included
+  // (field_fwd_bf16x.hip: k_render_pair_bf16x); with the weight image reused (rendering loops) it is the only launch of the call
+  const bool pair = bf16x && Nc == 64 && Nf == 128 && pair_bf16(B);
   if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED) && !one_prep) {
     ProfScope ps(NERF_HIP_K_PACK, st, &pc);
     if (bf16 || split) HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));  // fp32 W_fold, b_fold for the bf16 / split packers (bf16_common.h)
@@ -324,17 +327,21 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ra.b_fold = at<float>(ws, L.fold);
   ra.t_c = at<float>(ws, L.t_c);
   ra.status = at<unsigned>(ws, L.status);  // zeroed by the kernel (the later kernels OR their flags into it)
+  static std::atomic<unsigned> g_token{0};
+  unsigned token = ++g_token;
+  if ((token & 0xffffffu) == 0) token = ++g_token;  // (its low 24 bits stamp the status word of the pair kernel: never 0)
   if (one_prep) {
     const bool pack = !(flags & NERF_HIP_WEIGHTS_UNCHANGED);
-    static std::atomic<unsigned> g_token{0};
-    unsigned token = ++g_token;
-    if (token == 0) token = ++g_token;
-    ProfScope ps(pack ? NERF_HIP_K_PACK : NERF_HIP_K_RAYS, st, &pc);
-    HIP_TRY(launch_prep_bf16(w, at<float>(ws, L.fold), pack ? at<unsigned char>(ws, L.packed_bf) : nullptr, bf16x ? 1 : 0,
-                             pack && save ? at<unsigned char>(ws, L.packed_bf_bwd) : nullptr,
-                             reinterpret_cast<unsigned*>(at<float>(ws, L.fold) + FOLD_FLOATS), token,
-                             at<unsigned>(ws, L.status) + STATUS_STICKY_WORD, ra, st));
-  } else {
+    RaysArgs rp = ra;
+    if (pair) rp.B = 0;  // the pair kernel makes its own ray records
+    if (pack || rp.B > 0) {
+      ProfScope ps(pack ? NERF_HIP_K_PACK : NERF_HIP_K_RAYS, st, &pc);
+      HIP_TRY(launch_prep_bf16(w, at<float>(ws, L.fold), pack ? at<unsigned char>(ws, L.packed_bf) : nullptr, bf16x ? 1 : 0,
+                               pack && save ? at<unsigned char>(ws, L.packed_bf_bwd) : nullptr,
+                               reinterpret_cast<unsigned*>(at<float>(ws, L.fold) + FOLD_FLOATS), token,
+                               at<unsigned>(ws, L.status) + STATUS_STICKY_WORD, rp, st));
+    }
+  } else if (!pair) {
     ProfScope ps(NERF_HIP_K_RAYS, st, &pc);
     HIP_TRY(launch_rays(ra, st));
   }
@@ -368,10 +375,10 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   }
   // SMALL bf16-MLP inference batches at the shipped sample counts: ONE launch renders every ray pair end to end (field_fwd_bf16x.hip:
   // k_render_pair_bf16x -- both field passes, coarse composite + resampling, merge + sorts + composite; bit-identical pixels)
-  if (bf16x && Nc == 64 && Nf == 128 && pair_bf16(B)) {
+  if (pair) {
     PairArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.wbf = at<unsigned char>(ws, L.packed_bf); pa.rayf = at<float>(ws, L.rayf); pa.t_c = at<float>(ws, L.t_c); pa.B = B;
+    pa.wbf = at<unsigned char>(ws, L.packed_bf); pa.rays = ra; pa.rays.status = nullptr; pa.B = B; pa.gen = token & 0xffffffu;
     if (ray0_near_far) { pa.ray0_override = 1; pa.near0 = ray0_near_far[0]; pa.far0 = ray0_near_far[1]; }
     pa.last = last_delta; pa.C_coarse = C_coarse; pa.C_fine = C_fine;
     pa.status = at<uint32_t>(ws, L.status); pa.sticky = at<uint32_t>(ws, L.status) + STATUS_STICKY_WORD;
@@ -718,8 +725,12 @@ int nerf_hip_ray_loss(const float* C_coarse, const float* C_fine, const float* C
 int nerf_hip_read_status(const void* ws, size_t ws_bytes, uint32_t* status, void* stream) {
   if (!ws || !status || ws_bytes < 256) return fail(NERF_HIP_ERR_ARG, "null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  HIP_TRY(hipMemcpyAsync(status, ws, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  uint32_t w[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(w, ws, sizeof(w), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  // legacy scheme: word 0 (zeroed by the call's first kernel); stamped scheme (common.h STATUS_*): the flags count only with this call's stamp
+  if (w[STATUS_SCHEME_WORD] == 1u) *status = ((w[STATUS_STAMPED_WORD] >> 8) == w[STATUS_GEN_WORD]) ? (w[STATUS_STAMPED_WORD] & 0xffu) : 0u;
+  else *status = w[0];
   return NERF_HIP_OK;
 }
 

@@ -14,6 +14,11 @@ constexpr int L_POINT = 10;
 constexpr int L_DIR = 4;
 constexpr int HALF = 128;       // width of the colour branch (nerf.py:98)
 constexpr int TM = 64;          // samples per workgroup tile of the field kernels
+// Status region = 64 u32 words.  Word 0: the flags of the last forward in the LEGACY scheme (zeroed by the call's first kernel, OR-ed by later
+// ones).  A forward whose first kernel is also the one that sets flags (the ray-pair kernel of small bf16 inference batches: one launch per
+// call) cannot zero anything first; it uses the STAMPED scheme: word 1 = the call's generation, word 2 = 1, word 3 = (generation << 8) | flags,
+// valid only if its generation is word 1's.  nerf_hip_read_status decodes whichever scheme word 2 names (the legacy kernels zero it).
+constexpr int STATUS_GEN_WORD = 1, STATUS_SCHEME_WORD = 2, STATUS_STAMPED_WORD = 3;
 constexpr int STATUS_STICKY_WORD = 32;  // status region = 64 u32 words: [0, 32) cleared by every forward, [32, 64) only by the caller (nerf_hip_read_status_sticky)
 constexpr int DBG_WORDS = 16384;   // u64 words of the workspace's diagnostic area (make stamps)
 constexpr int DUMP_ROWS = 64;   // extra rows behind every saved tensor / gradient buffer: lanes past the end of a pass store there, unpredicated

@@ -19,6 +19,7 @@
 #include "bf16_stream.h"
 #include "bf16_weights.h"
 #include "ray_parts.h"
+#include "prep_parts.h"
 
 namespace nerf {
 
@@ -283,6 +284,22 @@ constexpr int PR_SIGF = PR_TF + 2 * PAIR_NF;
 constexpr int PR_RGBF = PR_SIGF + 2 * PAIR_NF;
 static_assert((PR_RGBF + 6 * PAIR_NF) * 4 <= BF_BIAS_BYTES && PR_SIGC >= 32 * BF_NBIAS_TILES, "results live behind the bias tiles");
 
+// element `k` (lane-varying) of a register array without a scratch round trip: a select chain
+__device__ __forceinline__ float rf_lane(const float (&rf)[RAYF], int k) {
+  float v = rf[0];
+#pragma unroll
+  for (int j = 1; j < RAYF; ++j) v = (k == j) ? rf[j] : v;
+  return v;
+}
+// flags |= bits in a word that carries the generation of the call it belongs to: (gen << 8) | flags.  A word of another generation (an
+// earlier call's, or garbage) is replaced.  Rare (a ray met the reference's exit(0) condition), so the compare-and-swap loop costs nothing.
+__device__ __forceinline__ void status_stamp_or(unsigned* word, unsigned gen, unsigned bits) {
+  unsigned cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    const unsigned want = ((cur >> 8) == gen) ? (cur | bits) : ((gen << 8) | bits);
+    if (__hip_atomic_compare_exchange_strong(word, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+  }
+}
 __device__ __forceinline__ void wave_lds_fence() {  // this wave's LDS writes are visible to its own later reads (no workgroup barrier)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
@@ -316,9 +333,10 @@ __device__ __forceinline__ void pair_coarse_pass(const PairArgs& a, const BfCtx&
     const int n = c.lane & 15;
     const int s = 16 * c.wv + n, rl = s >> 6, i = s & 63;
     const int ray = min(r0 + rl, a.B - 1);
-    const float* rf = a.rayf + (size_t)ray * RAYF;
+    float rf[RAYF];  // the ray record in registers: what k_rays would have left in the workspace (same function, same bits)
+    ray_record(a.rays, ray, rf);
     float p[1][3], dw[1][3];
-    sample_point(rf, a.t_c[(size_t)ray * PAIR_NC + i], p[0]);
+    sample_point(rf, coarse_depth(rf[RF_NEAR], rf[RF_FAR], rf[RF_STEP], i, PAIR_NC), p[0]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) dw[0][k] = rf[RF_DWRD + k];
 #pragma unroll
@@ -347,7 +365,8 @@ __device__ __forceinline__ void pair_fine_pass(const PairArgs& a, const BfCtx& c
     for (int h = 0; h < 2; ++h) {
       const int s = 32 * c.wv + 16 * h + n, rl = s >> 7;
       const int ray = min(r0 + rl, a.B - 1);
-      const float* rf = a.rayf + (size_t)ray * RAYF;
+      float rf[RAYF];
+      ray_record(a.rays, ray, rf);
       sample_point(rf, res[PR_TF + s], p[h]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) dw[h][k] = rf[RF_DWRD + k];
@@ -386,6 +405,13 @@ __global__ __launch_bounds__(BF_WG, 1) void k_render_pair_bf16x(const PairArgs a
   c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* const res = reinterpret_cast<float*>(lds);
   const int r0 = 2 * blockIdx.x;  // this workgroup's rays r0, r0 + 1 (the second one may lie behind the batch: computed on a copy, not stored)
+  // No kernel runs in front of this one in a rendering loop (the ray records are made here, the weight image is reused), so nobody has
+  // zeroed the workspace's status word: this call's flags are STAMPED with its generation instead (common.h STATUS_*: the reader takes
+  // them only if the stamp is this call's)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.status) {
+    a.status[STATUS_GEN_WORD] = a.gen;
+    a.status[STATUS_SCHEME_WORD] = 1u;
+  }
 
   pair_coarse_pass(a, c, lds, r0);
   __syncthreads();  // the pair's coarse sigma / rgb are in LDS; nobody reads the ring any more
@@ -395,22 +421,28 @@ __global__ __launch_bounds__(BF_WG, 1) void k_render_pair_bf16x(const PairArgs a
     const int rl = c.wv, ray_raw = r0 + rl;
     const bool live = ray_raw < a.B;
     const int ray = live ? ray_raw : a.B - 1;
-    const float* rf = a.rayf + (size_t)ray * RAYF;
+    float rf[RAYF];
+    ray_record(a.rays, ray, rf);
     const float near = rf[RF_NEAR], far = rf[RF_FAR];
-    const float n0 = a.ray0_override ? a.near0 : a.rayf[RF_NEAR], f0 = a.ray0_override ? a.far0 : a.rayf[RF_FAR];
+    // quirk Q6: the coarse spacing of the batch's ray 0 (pose row 0 of this call, or the caller's global ray 0)
+    const float n0 = a.ray0_override ? a.near0 : a.rays.pb[15], f0 = a.ray0_override ? a.far0 : a.rays.pb[16];
     const float delta0 = ray0_spacing(n0, f0, PAIR_NC);
-    float* scr = reinterpret_cast<float*>(lds + BF_BIAS_BYTES) + rl * 3 * PAIR_NC;
-    float* sw = scr, *scdf = scr + PAIR_NC, *stc = scr + 2 * PAIR_NC;
+    float* scr = reinterpret_cast<float*>(lds + BF_BIAS_BYTES) + rl * 4 * PAIR_NC;
+    float* sw = scr, *scdf = scr + PAIR_NC, *stc = scr + 2 * PAIR_NC, *stin = scr + 3 * PAIR_NC;
     const size_t g0 = (size_t)ray * PAIR_NC;
+    stin[lane] = coarse_depth(near, far, rf[RF_STEP], lane, PAIR_NC);  // the ray's coarse depths (k_rays' t_c)
+    wave_lds_fence();
     float lo, hi;
-    coarse_ray_weights(res + PR_SIGC + PAIR_NC * rl, res + PR_RGBC + 3 * PAIR_NC * rl, a.t_c + g0, near, far, PAIR_NC, lane, sw, scdf, stc,
+    coarse_ray_weights(res + PR_SIGC + PAIR_NC * rl, res + PR_RGBC + 3 * PAIR_NC * rl, stin, near, far, PAIR_NC, lane, sw, scdf, stc,
                        (live && a.w_c) ? a.w_c + g0 : nullptr, live ? a.C_coarse + (size_t)ray * 3 : nullptr, lo, hi);
     wave_lds_fence();
     const bool bad = coarse_ray_resample(sw, scdf, stc, lo, hi, delta0, PAIR_NC, PAIR_NF, lane, res + PR_TF + PAIR_NF * rl);
-    if (live && bad && a.status) atomicOr(a.status, 1u);
+    if (live && bad && a.status) status_stamp_or(a.status + STATUS_STAMPED_WORD, a.gen, 1u);
     if (live && bad && a.sticky) atomicOr(a.sticky, 1u);
     wave_lds_fence();
-    if (live) {  // the workspace's per-sample buffers of the coarse pass and the fine depths (introspection; 2.5 KB per ray)
+    if (live) {  // the workspace's per-ray / per-sample buffers of the coarse pass and the fine depths (introspection; 2.9 KB per ray)
+      if (lane < RAYF && a.rays.rayf) a.rays.rayf[(size_t)ray * RAYF + lane] = rf_lane(rf, lane);
+      if (a.rays.t_c) a.rays.t_c[g0 + lane] = stin[lane];
       if (a.sig_c) a.sig_c[g0 + lane] = res[PR_SIGC + PAIR_NC * rl + lane];
       if (a.rgb_c)
 #pragma unroll
@@ -435,11 +467,12 @@ __global__ __launch_bounds__(BF_WG, 1) void k_render_pair_bf16x(const PairArgs a
     const int ray = live ? ray_raw : a.B - 1;
     constexpr int P = 256, N = PAIR_NC + PAIR_NF;
     float* val = reinterpret_cast<float*>(lds + BF_BIAS_BYTES) + rl * 5 * P;
-    const size_t g0 = (size_t)ray * PAIR_NC;
+    const float nearm = a.rays.pb[(size_t)ray * 17 + 15], farm = a.rays.pb[(size_t)ray * 17 + 16];
+    const float stepm = (farm - nearm) / (float)(PAIR_NC - 1);  // (= the ray record's RF_STEP)
     for (int i = lane; i < P; i += 64) {  // channel 0 = t, 1..3 = rgb, 4 = sigma (k_merge's load, from LDS)
       float v[5];
       if (i < PAIR_NC) {
-        v[0] = a.t_c[g0 + i];
+        v[0] = coarse_depth(nearm, farm, stepm, i, PAIR_NC);
         v[1] = res[PR_RGBC + 3 * (PAIR_NC * rl + i)]; v[2] = res[PR_RGBC + 3 * (PAIR_NC * rl + i) + 1]; v[3] = res[PR_RGBC + 3 * (PAIR_NC * rl + i) + 2];
         v[4] = res[PR_SIGC + PAIR_NC * rl + i];
       } else if (i < N) {

@@ -117,15 +117,15 @@ hipError_t launch_field_fwd_bf16x(const FieldArgs& a, hipStream_t st);  // infer
 // small batches, Nc = 64 / Nf = 128: the whole inference forward of a ray PAIR per workgroup in one launch (field_fwd_bf16x.hip)
 struct PairArgs {
   const unsigned char* wbf;   // 16x16x32 weight image
-  const float* rayf;          // [B][RAYF]
-  const float* t_c;           // [B][64]
+  RaysArgs rays;              // row, col, pb, K (Nc = 64): the ray records are made in the kernel; rays.rayf / rays.t_c (may be null) get copies
   int B;
+  unsigned gen;               // this call's generation (24 bits, never 0): stamps the status flags (common.h STATUS_*)
   int ray0_override;          // quirk Q6: 1 = near0 / far0 below are the batch's GLOBAL ray 0's, 0 = this call's ray 0
   float near0, far0;
   float last;                 // nerf.py:286
   float* C_coarse;            // [B][3]
   float* C_fine;              // [B][3]
-  uint32_t* status;
+  uint32_t* status;           // the workspace's status words (word 0 of the region)
   uint32_t* sticky;
   float *sig_c, *rgb_c, *w_c, *t_f, *sig_f, *rgb_f;  // the workspace's per-sample buffers (written for introspection; may be null)
 };

@@ -53,10 +53,9 @@ __device__ __forceinline__ void fold_block(const Weights24& w, float* __restrict
 
 // k_rays: nerf.py:52-67 (pose split), 186-197 (pixel -> unit camera dir), 211 (world dir), 288 (coarse
 // depths, numpy.linspace in fp32) and the gamma_d half of dir_info (nerf.py:118) which is constant per ray.
-// one ray by 128 consecutive threads (tid = 0..127 inside the group); the dvec part ends in a __syncthreads(): with a.dvec every thread
-// of the block must call this
-__device__ __forceinline__ void ray_block(const RaysArgs& a, const int ray, const int tid, float* gd /* LDS, DIR_DIM floats per group */) {
-  if (a.status && ray == 0 && tid < STATUS_STICKY_WORD) a.status[tid] = 0u;  // the forward's status words start clean (instead of a memset node of their own); the sticky ones stay
+// The ray record of one ray in registers (every calling lane computes the same values): rec[0..8] R row-major, [9..11] o, [12..14] d_cam,
+// [15..17] d_wrd, [18] near, [19] far, [20] (far - near)/(Nc - 1), [21] (far - near)/Nc (common.h RF_*).
+__device__ __forceinline__ void ray_record(const RaysArgs& a, const int ray, float (&rec)[RAYF]) {
   const float* pb = a.pb + (size_t)ray * 17;
   // x <- row, y <- column (quirk Q2)
   const float x = (float)a.row[ray], y = (float)a.col[ray];
@@ -74,37 +73,49 @@ __device__ __forceinline__ void ray_block(const RaysArgs& a, const int ray, cons
 #pragma unroll
   for (int c = 0; c < 3; ++c) dw[c] = (pb[5 * c] * d[0] + pb[5 * c + 1] * d[1]) + pb[5 * c + 2] * d[2];
   const float near = pb[15], far = pb[16];
-  const float step = (far - near) / (float)(a.Nc - 1);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rec[RF_R + 3 * c + k] = pb[5 * c + k];
+    rec[RF_O + c] = pb[5 * c + 3];
+    rec[RF_DCAM + c] = d[c];
+    rec[RF_DWRD + c] = dw[c];
+  }
+  rec[RF_NEAR] = near;
+  rec[RF_FAR] = far;
+  rec[RF_STEP] = (far - near) / (float)(a.Nc - 1);
+  rec[RF_DELTA] = (far - near) / (float)a.Nc;  // quirk Q5 (nerf.py:293)
+  rec[22] = 0.f;
+  rec[23] = 0.f;
+}
+// coarse depth i of a ray (nerf.py:288: numpy.linspace(near, far, Nc) in fp32 -- separate multiply and add, the end point exact)
+__device__ __forceinline__ float coarse_depth(float near, float far, float step, int i, int Nc) { return (i == Nc - 1) ? far : ((float)i * step + near); }
+
+// one ray by 128 consecutive threads (tid = 0..127 inside the group); the dvec part ends in a __syncthreads(): with a.dvec every thread
+// of the block must call this
+__device__ __forceinline__ void ray_block(const RaysArgs& a, const int ray, const int tid, float* gd /* LDS, DIR_DIM floats per group */) {
+  if (a.status && ray == 0 && tid < STATUS_STICKY_WORD) a.status[tid] = 0u;  // the forward's status words start clean (instead of a memset node of their own); the sticky ones stay
+  float rec[RAYF];
+  ray_record(a, ray, rec);
+  const float near = rec[RF_NEAR], far = rec[RF_FAR], step = rec[RF_STEP];
   if (tid == 0) {
     if (a.rayf) {
       float* rf = a.rayf + (size_t)ray * RAYF;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) rf[RF_R + 3 * c + k] = pb[5 * c + k];
-        rf[RF_O + c] = pb[5 * c + 3];
-        rf[RF_DCAM + c] = d[c];
-        rf[RF_DWRD + c] = dw[c];
-      }
-      rf[RF_NEAR] = near;
-      rf[RF_FAR] = far;
-      rf[RF_STEP] = step;
-      rf[RF_DELTA] = (far - near) / (float)a.Nc;  // quirk Q5 (nerf.py:293)
-      rf[22] = 0.f;
-      rf[23] = 0.f;
+      for (int k = 0; k < RAYF; ++k) rf[k] = rec[k];
     }
     if (a.d_cam)
-      for (int c = 0; c < 3; ++c) a.d_cam[(size_t)ray * 3 + c] = d[c];
+      for (int c = 0; c < 3; ++c) a.d_cam[(size_t)ray * 3 + c] = rec[RF_DCAM + c];
     if (a.d_wrd)
-      for (int c = 0; c < 3; ++c) a.d_wrd[(size_t)ray * 3 + c] = dw[c];
+      for (int c = 0; c < 3; ++c) a.d_wrd[(size_t)ray * 3 + c] = rec[RF_DWRD + c];
   }
   if (a.t_c) {
-    for (int i = tid; i < a.Nc; i += 128) a.t_c[(size_t)ray * a.Nc + i] = (i == a.Nc - 1) ? far : ((float)i * step + near);
+    for (int i = tid; i < a.Nc; i += 128) a.t_c[(size_t)ray * a.Nc + i] = coarse_depth(near, far, step, i, a.Nc);
   }
   if (a.dvec) {
     if (tid < 12) {
       const int c = tid >> 2, l = tid & 3;
-      const float ph = dw[c] * __uint_as_float(kFreqDirBits[l]);
+      const float ph = rec[RF_DWRD + c] * __uint_as_float(kFreqDirBits[l]);
       gd[c * 8 + 2 * l] = sinf(ph);
       gd[c * 8 + 2 * l + 1] = cosf(ph);
     }

@@ -423,13 +423,17 @@ def test_weight_gradients_in_one_launch_equal_a_launch_per_product(tmp_path):
 def test_pair_kernel_equals_separate_launches(tmp_path):
     """field_fwd_bf16x.hip k_render_pair_bf16x (small bf16-MLP inference batches, Nc = 64 / Nf = 128): both field passes, the coarse
     composite + resampling and the merge + channel sorts + composite of a ray PAIR in one workgroup and ONE launch, against the four
-    separate launches (NERF_PAIR_BF16=0, a process of its own).  Same functions (bx_field_pass, ray_parts.h), so the same bits: the two
-    colours, every per-sample buffer of the workspace, the status word; an odd batch (the last workgroup holds ONE ray), a shard that is
+    separate launches (NERF_PAIR_BF16=0, a process of its own) -- ray records made in the kernel too, so a rendering loop is ONE launch per
+    call.  Same functions (ray_record, bx_field_pass, ray_parts.h), so the same bits: the two colours, the ray records and every per-sample
+    buffer of the workspace, the status word; an odd batch (the last workgroup holds ONE ray), a shard that is
     handed the global ray 0's near / far, a ray that meets the reference's exit(0) condition."""
     for B in (97, 256):
         one = _variant(tmp_path, f"pair1_{B}", {"NERF_PAIR_BF16": "1"}, B)
         sep = _variant(tmp_path, f"pair0_{B}", {"NERF_PAIR_BF16": "0"}, B)
-        for k in ("Ic", "If", "Fc", "Ff", "Sc", "Sf", "infer_sig_c", "infer_rgb_c", "infer_w_c", "infer_t_f", "infer_sig_f", "infer_rgb_f"):
+        for k in ("Ic", "If", "Fc", "Ff", "Sc", "Sf", "infer_rayf", "infer_t_c", "infer_sig_c", "infer_rgb_c", "infer_w_c", "infer_t_f", "infer_sig_f",
+                  "infer_rgb_f"):
             assert torch.equal(one[k], sep[k]), (B, k)
+        # the status word: stamped with the call's generation in the pair kernel (no kernel in front of it to zero a word), legacy otherwise
         assert one["S_fault"] is True and sep["S_fault"] is True
+        assert one["S_fault_after_healthy"] is False and sep["S_fault_after_healthy"] is False
         assert one["sticky"] & 2 == 0

@@ -57,7 +57,8 @@ def main():
     wsi = m.last_workspace
     res["infer_packed_bf"] = region("packed_bf", img_bytes, _abi.BF16_MLP, wsi)
     res["Ic"], res["If"] = Ic.cpu(), If.cpu()
-    for name, n in (("sig_c", B * Nc), ("rgb_c", B * Nc * 3), ("w_c", B * Nc), ("t_f", B * Nf), ("sig_f", B * Nf), ("rgb_f", B * Nf * 3)):
+    for name, n in (("rayf", B * 24), ("t_c", B * Nc), ("sig_c", B * Nc), ("rgb_c", B * Nc * 3), ("w_c", B * Nc), ("t_f", B * Nf), ("sig_f", B * Nf),
+                    ("rgb_f", B * Nf * 3)):
         res["infer_" + name] = region(name, n * 4, _abi.BF16_MLP, wsi)  # the workspace's per-sample buffers of the inference call
     # a shard that does not start at the batch's ray 0 (quirk Q6: the global ray 0's near / far handed in) and the status word
     m.ray0_near_far = (float(pb[0, 15]) * 0.9, float(pb[0, 16]) * 1.1)
@@ -67,6 +68,9 @@ def main():
         Sc, Sf = m(row, col, pb_bad, K)
     res["Sc"], res["Sf"], res["S_fault"] = Sc.cpu(), Sf.cpu(), bool(m.resample_fault())
     m.ray0_near_far = None
+    with torch.no_grad():  # a healthy call on the same workspace right behind the faulty one: its status must be clean
+        m(row, col, pb, K)
+    res["S_fault_after_healthy"] = bool(m.resample_fault())
     # frozen rendering loop: the second call reuses the image and only makes the ray records
     with torch.no_grad(), m.frozen_weights():
         m(row, col, pb, K)
