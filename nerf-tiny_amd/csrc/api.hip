@@ -64,9 +64,10 @@ bool prep_bf16_disabled() {
   static const bool off = [] { const char* e = getenv("NERF_PREP_BF16"); return e && atoi(e) == 0; }();
   return off;
 }
-// bf16-MLP inference: the ray-pair kernel up to this many rays (one workgroup per pair: at most two rounds over the 256 CUs).
+// bf16-MLP inference: the ray-pair kernel up to this many rays (one workgroup per pair = ONE round over the 256 CUs; measured: 400 rays
+// -9 %, 512 -6..-9 %, 1024 rays -- a second, half-empty round whose coarse phases run 16-sample waves -- +17 %).
 // NERF_PAIR_BF16=0 / 1 overrides the choice (A/B measurements only)
-constexpr int PAIR_BF16_MAX_RAYS = 1024;
+constexpr int PAIR_BF16_MAX_RAYS = 512;
 bool pair_bf16(int B) {
   static const int forced = [] { const char* e = getenv("NERF_PAIR_BF16"); return e ? atoi(e) : -1; }();
   return forced >= 0 ? forced != 0 : B <= PAIR_BF16_MAX_RAYS;

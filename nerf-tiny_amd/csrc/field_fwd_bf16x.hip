@@ -459,46 +459,55 @@ __global__ __launch_bounds__(BF_WG, 1) void k_render_pair_bf16x(const PairArgs a
     pair_fine_pass(a, c2, lds2, r0);
   }
   __syncthreads();  // the pair's fine sigma / rgb are in LDS; the ring is free
-  // ================= merge + five channel sorts + composite (nerf.py:302-321): waves 0, 1, one ray each, val [5][256] in the ring
-  if (c.wv < 2) {
-    const int lane = lane_id_builtin();
-    const int rl = c.wv, ray_raw = r0 + rl;
-    const bool live = ray_raw < a.B;
-    const int ray = live ? ray_raw : a.B - 1;
+  // ================= merge + five channel sorts + composite (nerf.py:302-321).  The pair's TEN channel sorts (2 rays x t, r, g, b, sigma: five
+  // independent sorts per ray, quirk Q1) are dealt out over the eight waves -- each sorts one 256-slot channel in registers, the same network
+  // as inside k_merge's five-channel sort -- and leaves it in val [2][5][256] in the ring; then waves 0, 1 composite one ray each.
+  {
     constexpr int P = 256, N = PAIR_NC + PAIR_NF;
-    float* val = reinterpret_cast<float*>(lds + BF_BIAS_BYTES) + rl * 5 * P;
-    const float nearm = a.rays.pb[(size_t)ray * 17 + 15], farm = a.rays.pb[(size_t)ray * 17 + 16];
-    const float stepm = (farm - nearm) / (float)(PAIR_NC - 1);  // (= the ray record's RF_STEP)
-    for (int i = lane; i < P; i += 64) {  // channel 0 = t, 1..3 = rgb, 4 = sigma (k_merge's load, from LDS)
-      float v[5];
-      if (i < PAIR_NC) {
-        v[0] = coarse_depth(nearm, farm, stepm, i, PAIR_NC);
-        v[1] = res[PR_RGBC + 3 * (PAIR_NC * rl + i)]; v[2] = res[PR_RGBC + 3 * (PAIR_NC * rl + i) + 1]; v[3] = res[PR_RGBC + 3 * (PAIR_NC * rl + i) + 2];
-        v[4] = res[PR_SIGC + PAIR_NC * rl + i];
-      } else if (i < N) {
-        const int j = PAIR_NF * rl + (i - PAIR_NC);
-        v[0] = res[PR_TF + j];
-        v[1] = res[PR_RGBF + 3 * j]; v[2] = res[PR_RGBF + 3 * j + 1]; v[3] = res[PR_RGBF + 3 * j + 2];
-        v[4] = res[PR_SIGF + j];
-      } else {
-        v[0] = v[1] = v[2] = v[3] = v[4] = __builtin_nanf("");
+    float* const val_all = reinterpret_cast<float*>(lds + BF_BIAS_BYTES);
+    const int lane = lane_id_builtin();
+    for (int j = c.wv; j < 10; j += 8) {
+      const int rl = j / 5, ch = j - 5 * rl;
+      const int ray = min(r0 + rl, a.B - 1);
+      const float nearm = a.rays.pb[(size_t)ray * 17 + 15], farm = a.rays.pb[(size_t)ray * 17 + 16];
+      const float stepm = (farm - nearm) / (float)(PAIR_NC - 1);  // (= the ray record's RF_STEP)
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // slot i of the merged bundle: coarse samples first, then fine (k_merge's load), padding = NaN = the maximum key
+        const int i = 4 * lane + r;
+        float x;
+        if (i < PAIR_NC) {
+          const int sc = PAIR_NC * rl + i;
+          x = ch == 0 ? coarse_depth(nearm, farm, stepm, i, PAIR_NC) : ch == 4 ? res[PR_SIGC + sc] : res[PR_RGBC + 3 * sc + (ch - 1)];
+        } else if (i < N) {
+          const int sf = PAIR_NF * rl + (i - PAIR_NC);
+          x = ch == 0 ? res[PR_TF + sf] : ch == 4 ? res[PR_SIGF + sf] : res[PR_RGBF + 3 * sf + (ch - 1)];
+        } else {
+          x = __builtin_nanf("");
+        }
+        v[r] = x;
       }
-#pragma unroll
-      for (int ch = 0; ch < 5; ++ch) val[ch * P + i] = v[ch];
+      sort256_one_channel(v, lane);
+      *reinterpret_cast<float4*>(val_all + (rl * 5 + ch) * P + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    if (live) {  // the workspace's per-sample buffers of the fine pass (introspection)
-      const size_t gf = (size_t)ray * PAIR_NF;
+    __syncthreads();
+    if (c.wv < 2) {
+      const int rl = c.wv, ray_raw = r0 + rl;
+      const bool live = ray_raw < a.B;
+      const int ray = live ? ray_raw : a.B - 1;
+      if (live) {  // the workspace's per-sample buffers of the fine pass (introspection)
+        const size_t gf = (size_t)ray * PAIR_NF;
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (a.sig_f) a.sig_f[gf + 64 * k + lane] = res[PR_SIGF + PAIR_NF * rl + 64 * k + lane];
+        for (int k = 0; k < 2; ++k)
+          if (a.sig_f) a.sig_f[gf + 64 * k + lane] = res[PR_SIGF + PAIR_NF * rl + 64 * k + lane];
 #pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (a.rgb_f) a.rgb_f[gf * 3 + 64 * k + lane] = res[PR_RGBF + 3 * PAIR_NF * rl + 64 * k + lane];
+        for (int k = 0; k < 6; ++k)
+          if (a.rgb_f) a.rgb_f[gf * 3 + 64 * k + lane] = res[PR_RGBF + 3 * PAIR_NF * rl + 64 * k + lane];
+      }
+      float cf[3];
+      float* const cout = live ? a.C_fine + (size_t)ray * 3 : cf;  // (a dead second ray: composited into registers nobody reads)
+      merge_ray_composite<false>(val_all + rl * 5 * P, nullptr, P, N, a.last, lane, nullptr, nullptr, nullptr, cout);
     }
-    wave_lds_fence();
-    float cf[3];
-    float* const cout = live ? a.C_fine + (size_t)ray * 3 : cf;  // (a dead second ray: composited into registers nobody reads)
-    merge_ray_sort_composite<false>(val, nullptr, P, N, a.last, lane, nullptr, nullptr, nullptr, cout, [] { wave_lds_fence(); });
   }
 }
 

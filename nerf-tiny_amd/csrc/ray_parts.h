@@ -139,15 +139,15 @@ __device__ __forceinline__ unsigned sort_key(float x) {
 }
 __device__ __forceinline__ float sort_unkey(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
 
-template <bool WITH_IDX, int K, int J>
-__device__ __forceinline__ void sortreg_stage(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
+template <bool WITH_IDX, int K, int J, int NCH>
+__device__ __forceinline__ void sortreg_stage(unsigned (&key)[NCH][4], unsigned (&ix)[NCH][4], int lane) {
   if constexpr (J >= 4) {
     constexpr int D = J / 4;
     const bool upper = (lane & D) != 0;
     const bool asc = K >= 256 ? true : ((4 * lane) & K) == 0;
     const bool flip = upper != !asc;  // take the partner's element iff (mine > partner's) != flip
 #pragma unroll
-    for (int c = 0; c < 5; ++c)
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const unsigned pk = lane_xor_get<D>(key[c][r]);
@@ -165,7 +165,7 @@ __device__ __forceinline__ void sortreg_stage(unsigned (&key)[5][4], unsigned (&
       }
   } else {
 #pragma unroll
-    for (int c = 0; c < 5; ++c)
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (r & J) continue;
@@ -186,15 +186,15 @@ __device__ __forceinline__ void sortreg_stage(unsigned (&key)[5][4], unsigned (&
       }
   }
 }
-template <bool WITH_IDX, int K, int J>
-__device__ __forceinline__ void sortreg_merge(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
-  sortreg_stage<WITH_IDX, K, J>(key, ix, lane);
-  if constexpr (J > 1) sortreg_merge<WITH_IDX, K, J / 2>(key, ix, lane);
+template <bool WITH_IDX, int K, int J, int NCH>
+__device__ __forceinline__ void sortreg_merge(unsigned (&key)[NCH][4], unsigned (&ix)[NCH][4], int lane) {
+  sortreg_stage<WITH_IDX, K, J, NCH>(key, ix, lane);
+  if constexpr (J > 1) sortreg_merge<WITH_IDX, K, J / 2, NCH>(key, ix, lane);
 }
-template <bool WITH_IDX, int K>
-__device__ __forceinline__ void sortreg_from(unsigned (&key)[5][4], unsigned (&ix)[5][4], int lane) {
-  sortreg_merge<WITH_IDX, K, K / 2>(key, ix, lane);
-  if constexpr (K < 256) sortreg_from<WITH_IDX, K * 2>(key, ix, lane);
+template <bool WITH_IDX, int K, int NCH>
+__device__ __forceinline__ void sortreg_from(unsigned (&key)[NCH][4], unsigned (&ix)[NCH][4], int lane) {
+  sortreg_merge<WITH_IDX, K, K / 2, NCH>(key, ix, lane);
+  if constexpr (K < 256) sortreg_from<WITH_IDX, K * 2, NCH>(key, ix, lane);
 }
 // val [5][256] floats (and idx [5][256] u16, WITH_IDX) in LDS: read as 4 slots per lane, sort, write back in sorted order
 template <bool WITH_IDX, class Sync>
@@ -207,7 +207,7 @@ __device__ __forceinline__ void sort256_regs(float* val, uint16_t* idx, int lane
 #pragma unroll
     for (int r = 0; r < 4; ++r) ix[c][r] = (unsigned)(4 * lane + r);  // (= what the loader wrote to idx)
   }
-  sortreg_from<WITH_IDX, 2>(key, ix, lane);
+  sortreg_from<WITH_IDX, 2, 5>(key, ix, lane);
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     *reinterpret_cast<float4*>(val + c * 256 + 4 * lane) =
@@ -222,6 +222,22 @@ __device__ __forceinline__ void sort256_regs(float* val, uint16_t* idx, int lane
   sync();
 }
 
+
+// ONE channel of 256 slots (values only): lane l holds slots 4l .. 4l+3 in v; the same network, the same compare-exchanges as a channel of
+// sort256_regs -- so a channel sorted alone (the ray-pair kernel deals a pair's ten channel sorts out over its eight waves) comes out
+// bit for bit as inside the five-channel sort.
+__device__ __forceinline__ void sort256_one_channel(float (&v)[4], int lane) {
+  unsigned key[1][4], ix[1][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { key[0][r] = sort_key(v[r]); ix[0][r] = 0u; }
+  sortreg_from<false, 2, 1>(key, ix, lane);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = sort_unkey(key[0][r]);
+}
+
+template <bool WITH_IDX>
+__device__ __forceinline__ void merge_ray_composite(const float* val, const uint16_t* idx, int P, int N, float last, int lane, float* w_out,
+                                                    float* bundle_out, uint16_t* perm_out, float* C_out);
 
 // nerf.py:302-321 behind the load: val [5][P] (channel 0 = t, 1..3 = rgb, 4 = sigma; slots >= N padded with NaN) and, WITH_IDX, idx [5][P]
 // = the original slot, in LDS -> five independent ascending channel sorts (quirk Q1), delta_i = t_{i+1} - t_i with the last = `last`,
@@ -261,7 +277,13 @@ __device__ __forceinline__ void merge_ray_sort_composite(float* val, uint16_t* i
       sync();
     }
   }
-  // composite over the sorted channels
+  merge_ray_composite<WITH_IDX>(val, idx, P, N, last, lane, w_out, bundle_out, perm_out, C_out);
+}
+
+// the composite over the SORTED channels val [5][P] (and idx): delta_i = t_{i+1} - t_i with the last = `last`, weights, C_fine[3]
+template <bool WITH_IDX>
+__device__ __forceinline__ void merge_ray_composite(const float* val, const uint16_t* idx, int P, int N, float last, int lane, float* w_out,
+                                                    float* bundle_out, uint16_t* perm_out, float* C_out) {
   double carry = 0.0;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   for (int base = 0; base < N; base += 64) {
