@@ -72,6 +72,13 @@ bool pair_bf16(int B) {
   static const int forced = [] { const char* e = getenv("NERF_PAIR_BF16"); return e ? atoi(e) : -1; }();
   return forced >= 0 ? forced != 0 : B <= PAIR_BF16_MAX_RAYS;
 }
+// large batches: the small-block products of the bf16 weight-gradient phase in one launch (see nerf_hip_backward_overlap).
+// NERF_DW_BF16_SMALLGROUP=0 / 1 / 2 selects the variant (A/B measurements); default below
+constexpr int DW_BF16_SMALL_GROUP_DEFAULT = 0;
+int dw_bf16_small_group() {
+  static const int v = [] { const char* e = getenv("NERF_DW_BF16_SMALLGROUP"); return e ? atoi(e) : DW_BF16_SMALL_GROUP_DEFAULT; }();
+  return v;
+}
 constexpr int DW_BF16_MULTI_MAX_WB = 5120;  // 853 rays x (64 + 128); measured: 400 rays -25 %, 512 -18 %, 1024 +-0, 2048 +10 %, 4096 +30 %
 bool dw_bf16_multi(int wb_tot) {
   static const int forced = [] { const char* e = getenv("NERF_DW_BF16_MULTI"); return e ? atoi(e) : -1; }();
@@ -605,6 +612,55 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
         late_reds();
       }
       if ((size_t)(end - at<float>(ws, L.bslabs)) > dw_bf16_slab_floats()) return fail(NERF_HIP_ERR_WORKSPACE, "bf16 slab space exceeded");
+      HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
+      FoldGradArgs fg;
+      fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
+      fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
+      HIP_TRY(launch_fold_grads(fg, st));
+      return NERF_HIP_OK;
+    }
+    // LARGE batches, the products with SMALL blocks (layer 0: 20 KiB per wave block, the folded dir_info product 28, the colour head 10): alone
+    // in a launch each is paced by the ring's per-block latency (3.4 / 4.3 / 3.8 TB/s against the 5.8 of the 256 x 256 products:
+    // profiles/r03_train_bf16_pmc.json); sharing ONE launch (k_dw_bf16_multi, workgroups dealt out by cost) their streams overlap.
+    // Variant 1: six | layer 4 | {layer 0, folded, colour}; 2: six | {layer 4, layer 0, folded, colour}; 0: a launch each (round 3).
+    // Without an early event only (the overlap needs layer 0 in front of the event and the other two behind it).
+    const int small_group = early_event ? 0 : dw_bf16_small_group();
+    if (small_group) {
+      static const int layers[6] = {1, 2, 3, 5, 6, 7};
+      const unsigned char* Gs[6];
+      const unsigned char* Xs[6];
+      for (int k = 0; k < 6; ++k) { Gs[k] = Gt(BG_L0 + layers[k]); Xs[k] = X(BS_H0 + layers[k] - 1); }
+      HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st));
+      for (int k = 0; k < 6; ++k)
+        red(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dw[2 * layers[k]], WIDTH, 0, dw[2 * layers[k] + 1]);
+      slabs += (size_t)6 * ns * 256 * 257;
+      DwBfProd pr[4];
+      memset(pr, 0, sizeof(pr));
+      int n = 0, i_l4 = -1;
+      if (small_group == 1) {
+        HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
+        red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
+        slabs += (size_t)ns * 256 * 321;
+      } else {
+        i_l4 = n;
+        pr[n++] = DwBfProd{Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, nullptr, 0};
+      }
+      const int i_l0 = n;
+      pr[n++] = DwBfProd{Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, nullptr, 0};
+      const int i_d = n;
+      pr[n++] = DwBfProd{Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), nullptr, 0};
+      const int i_c = n;
+      pr[n++] = DwBfProd{Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, nullptr, 0};
+      float* end = slabs;
+      HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, &end, st));
+      if ((size_t)(end - at<float>(ws, L.bslabs)) > dw_bf16_slab_floats()) return fail(NERF_HIP_ERR_WORKSPACE, "bf16 slab space exceeded");
+      if (i_l4 >= 0) red(pr[i_l4].slabs, pr[i_l4].nslab, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
+      red(pr[i_l0].slabs, pr[i_l0].nslab, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1]);
+      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR]);
+      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, 0, HALF, 32, WIDTH, at<float>(ws, L.mbuf), WIDTH, 0, nullptr);
+      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, HALF + 3, 1, 32, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr);
+      red(pr[i_c].slabs, pr[i_c].nslab, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR]);
+      red(pr[i_c].slabs, pr[i_c].nslab, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA]);
       HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
       FoldGradArgs fg;
       fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
