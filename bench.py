@@ -45,6 +45,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md chip tabl
 PEAK_BF16_MFMA_TFLOPS = 2500.0                   # same table: bf16 matrix, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
 N_PARAMS = 593_924
+FUSED_TRAIN_STEP = True  # train legs: NeRFModel.train_step (one library call per step); --autograd-step times the three-call autograd path
 RING_ALLREDUCE_MS_ESTIMATE = 0.060  # 30-60 us for the un-overlapped 2.27 MiB SUM all-reduce on an 8-GPU xGMI ring (upper end)
 
 
@@ -255,9 +256,12 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
             if bucket is None:
                 for p in model.network.parameters():
                     p.grad = None
-            Cc, Cf = model(row, col, pb, K)
-            loss = model.ray_loss(Cc, Cf, C_true)
-            loss.backward()
+            if FUSED_TRAIN_STEP:  # nerf.py:470-473 (forward, ray_loss, backward) as ONE library call: what NeRFRunner.trainer makes
+                model.train_step(row, col, pb, K, C_true)
+            else:                 # --autograd-step: the reference's three calls through torch.autograd (same kernels)
+                Cc, Cf = model(row, col, pb, K)
+                loss = model.ray_loss(Cc, Cf, C_true)
+                loss.backward()
             if bucket is not None and dist is not None:  # data-parallel trainer: ONE flat 2.27 MiB SUM all-reduce over RCCL/xGMI
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -571,11 +575,16 @@ def main():
     ap.add_argument("--split", action="store_true",
                     help="forward only: the opt-in split-fp32 inference mode (model.split_mlp) as the leg of the line (profiling runs; NOT the "
                          "driver's headline, which stays the exact-fp32 path)")
+    ap.add_argument("--autograd-step", action="store_true",
+                    help="train legs: forward, ray_loss, backward as three calls through torch.autograd (the reference's call surface) instead of "
+                         "NeRFModel.train_step, the one library call NeRFRunner.trainer makes (same kernels, same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the leg named by --mode/--mlp (profiling runs)")
     ap.add_argument("--dry", action="store_true", help="CPU rehearsal of the launcher + process group over gloo (no kernels; tests only)")
     args = ap.parse_args()
 
+    global FUSED_TRAIN_STEP
+    FUSED_TRAIN_STEP = not args.autograd_step
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -755,6 +764,8 @@ def main():
                                     "cfg2: lego-like 400x400 view, 4096-ray batches, 64 coarse + 128 fine samples, fp32, ")
                                    + "random-init 8x256 NeRF MLP (593,924 params)", "rays_per_step_per_gpu": b_local,
                        "mode": args.mode,
+                       "train_step": ("NeRFModel.train_step: forward + ray_loss + backward in one library call, as NeRFRunner.trainer does"
+                                      if FUSED_TRAIN_STEP else "three calls through torch.autograd (the reference's call surface)"),
                        "weights": ("re-packed every step (the optimizer changes them)" if head.train else
                                    "packed once per rendering loop (NeRFModel.frozen_weights, the form render() / display() use)"),
                        "parallelism": f"ray-batch x{world} (independent batches, no collective)" if not head.train else

@@ -37,8 +37,8 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 4 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap, NERF_HIP_SPLIT_MLP;
-                                  4: nerf_hip_read_status_sticky */
+#define NERF_HIP_ABI_VERSION 5 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap, NERF_HIP_SPLIT_MLP;
+                                  4: nerf_hip_read_status_sticky; 5: nerf_hip_train_step */
 
 enum {
   NERF_HIP_OK = 0,
@@ -135,6 +135,22 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
                               const float* ray0_near_far, int B, int Nc, int Nf, float last_delta,
                               float* const* dweights24, void* ws, size_t ws_bytes, int flags, void* stream,
                               void* early_event);
+
+/*
+ * One train step's device work in ONE call: nerf_hip_forward (with NERF_HIP_SAVE_FOR_BACKWARD), nerf_hip_ray_loss and
+ * nerf_hip_backward_overlap enqueued back to back -- the three calls the reference's loop makes at nerf.py:470-473
+ * (`model(...)`, `ray_loss`, `loss.backward()`), without the caller's interpreter between them (at a 400 / 512-ray batch the gaps
+ * between three separate calls are 3 % of the step).  Same kernels, same results as the three calls.
+ *   C_true            [B,3] f32   the batch's pixel colours
+ *   C_coarse, C_fine  [B,3] f32 out (may not be NULL)
+ *   loss              [1] f32 out
+ *   dweights24, early_event   as in nerf_hip_backward_overlap
+ *   flags             NERF_HIP_SAVE_FOR_BACKWARD is implied; ws sized for the flags INCLUDING it
+ */
+int nerf_hip_train_step(const float* const* weights24, const int64_t* row, const int64_t* col, const float* poses_bound,
+                        const float* K_inv9, const float* ray0_near_far, const float* C_true, int B, int Nc, int Nf, float last_delta,
+                        float* C_coarse, float* C_fine, float* loss, float* const* dweights24, void* ws, size_t ws_bytes, int flags,
+                        void* stream, void* early_event);
 
 /* ray_loss (nerf.py:325-331) and its gradient: loss[1] = sum (C_c-C*)^2 + sum (C_f-C*)^2,
  * dC_c = 2 (C_c - C*), dC_f = 2 (C_f - C*).  dC_* may be NULL. */

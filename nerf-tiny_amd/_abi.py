@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_HIP_LIB", os.path.join(_HERE, "libnerf_hip.so"))  # override: diagnostic builds only
 
-NERF_HIP_ABI_VERSION = 4
+NERF_HIP_ABI_VERSION = 5
 SAVE_FOR_BACKWARD = 1 << 0
 FORCE_TILE_KERNEL = 1 << 1
 BF16_MLP = 1 << 2
@@ -30,6 +30,7 @@ _PROTOS = {
     "nerf_hip_backward": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_size_t, C.c_int, _p]),
     "nerf_hip_backward_overlap": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_size_t, C.c_int, _p, _p]),
     "nerf_hip_ray_loss": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, _p]),
+    "nerf_hip_train_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, _p, _p, C.c_size_t, C.c_int, _p, _p]),
     "nerf_hip_read_status": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_uint32), _p]),
     "nerf_hip_read_status_sticky": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_int, _p]),
     "nerf_hip_profile_begin": (C.c_int, [C.c_int]),

@@ -182,6 +182,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
     L.drgb_f = take(b * Nf * 12);
     L.dsig_f = take(b * Nf * 4);
     L.dt_f = take(b * Nf * 4);
+    L.dC = take(b * 6 * 4);  // d loss / d C_coarse, d loss / d C_fine of nerf_hip_train_step
   }
   L.total = o;
   return L;
@@ -751,6 +752,24 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
     HIP_TRY(launch_small_grads(sg, slabs, st));  // (the slabs are free after the reduce: scratch of the gamma_d columns' two-step sum)
   }
   return NERF_HIP_OK;
+}
+
+int nerf_hip_train_step(const float* const* weights24, const int64_t* row, const int64_t* col, const float* poses_bound,
+                        const float* K_inv9, const float* ray0_near_far, const float* C_true, int B, int Nc, int Nf, float last_delta,
+                        float* C_coarse, float* C_fine, float* loss, float* const* dweights24, void* ws, size_t ws_bytes, int flags,
+                        void* stream, void* early_event) {
+  if (!C_true || !loss || !C_coarse || !C_fine) return fail(NERF_HIP_ERR_ARG, "null argument");
+  flags |= NERF_HIP_SAVE_FOR_BACKWARD;
+  if (int rc = check_weights(const_cast<const float* const*>(dweights24))) return rc;  // (before anything is enqueued)
+  if (int rc = nerf_hip_forward(weights24, row, col, poses_bound, K_inv9, ray0_near_far, B, Nc, Nf, last_delta, C_coarse, C_fine, ws, ws_bytes,
+                                flags, stream))
+    return rc;
+  const WsLayout L = layout(B, Nc, Nf, flags);
+  float* dCc = at<float>(ws, L.dC);
+  float* dCf = dCc + (size_t)B * 3;
+  if (int rc = nerf_hip_ray_loss(C_coarse, C_fine, C_true, B, loss, dCc, dCf, stream)) return rc;
+  return nerf_hip_backward_overlap(weights24, dCc, dCf, ray0_near_far, B, Nc, Nf, last_delta, dweights24, ws, ws_bytes,
+                                   flags & ~NERF_HIP_WEIGHTS_UNCHANGED, stream, early_event);
 }
 
 int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_t* offset) {

@@ -279,6 +279,58 @@ class NeRFModel(nn.Module):
             raise ResampleIndexError("resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253)")
         return C_c, C_f
 
+    def train_step(self, row, column, poses_bound, K_inv, C_true):
+        """The device work of one iteration of the reference's loop (nerf.py:470-473: ``model(...)``, ``ray_loss``, ``loss.backward()``) in ONE
+        library call (``nerf_hip_train_step``): the same kernels enqueued back to back without the interpreter between them -- at a 400 / 512-ray
+        batch three separate calls leave 3 % of the step in gaps.  Leaves the gradients of this batch in ``p.grad`` exactly as the autograd
+        path does -- fresh tensors, or the views of ``model.grad_bucket`` (overwrite semantics, ``pending`` set) -- and returns
+        ``(C_coarse, C_fine, loss)`` (detached; ``loss`` a 0-dim tensor).  Bit-identical to the three calls
+        (tests/test_gpu_train.py::test_fused_train_step_equals_autograd_path).  What ``NeRFRunner.trainer`` calls."""
+        ps = self._params()
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("NeRFModel runs only on a ROCm device (MI355X): model.to('cuda'); there is no CPU path")
+        if row.shape[0] != self.batch_ray:
+            raise ValueError(f"batch of {row.shape[0]} rays, model built for batch_ray={self.batch_ray} (nerf.py:172-176)")
+        B, Nc, Nf = row.shape[0], self.num_coarse, self.num_fine
+        K9 = _abi.f32_array(K_inv.detach().to("cpu", torch.float32).reshape(-1).tolist())
+        pb = poses_bound.to(torch.float).to(dev).contiguous()
+        row_d, col_d = row.to(dev, torch.int64).contiguous(), column.to(dev, torch.int64).contiguous()
+        Ct = C_true.to(dev, torch.float32).contiguous()
+        ray0 = _abi.f32_array(self.ray0_near_far) if self.ray0_near_far is not None else None
+        flags = _call_flags(self, True)
+        ws = self._workspace(B, flags)
+        bucket = self.grad_bucket
+        if bucket is not None:
+            if len(bucket.params) != len(ps) or any(a is not b for a, b in zip(bucket.params, ps)):
+                raise RuntimeError("model.grad_bucket was built for other parameters")
+            if bucket.pending:
+                raise RuntimeError("a second backward would overwrite the gradients of the previous one in model.grad_bucket before "
+                                   "they were used: bucket.allreduce_sum(), train.FusedAdam.step() / .zero_grad() release it; after any other "
+                                   "optimizer's step call bucket.consume()")
+            bucket.pending = True
+            grads = bucket.views
+        else:
+            grads = [torch.empty_like(p) for p in ps]
+        C_c = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        C_f = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        early = bucket.early_event_handle if bucket is not None else 0
+        _abi.check(_abi.lib().nerf_hip_train_step(_abi.ptr_array(ps), row_d.data_ptr(), col_d.data_ptr(), pb.data_ptr(), K9, ray0, Ct.data_ptr(),
+                                                  B, Nc, Nf, LAST_DELTA, C_c.data_ptr(), C_f.data_ptr(), loss.data_ptr(), _abi.ptr_array(grads),
+                                                  ws.data_ptr(), ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream, early or None))
+        self._last_ws = ws
+        self._ws_generation[flags] = self._ws_generation.get(flags, 0) + 1  # a graph recorded earlier on this slot is stale now
+        for p, g in zip(ps, grads):
+            if bucket is not None:
+                if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                    p.grad = g
+            else:
+                p.grad = g  # overwrite, like zero_grad(set_to_none=True); backward()
+        if self.check_resample and self.resample_fault():
+            raise ResampleIndexError("resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253)")
+        return C_c, C_f, loss.reshape(())
+
     def resample_fault(self) -> bool:
         """Did the most recent forward meet the reference's exit condition -- a ray whose resampling index falls outside [0, Nf-1], i.e.
         whose coarse weights all vanished (nerf.py:251-253: banner + exit(0))?  The device path clamps the index and goes on; this reads

@@ -144,9 +144,12 @@ def train_step_local(model, bucket: GradBucket, row, col, poses_bound, K_inv, C_
     model.ray0_near_far = ray0
     model.grad_bucket = bucket
     try:
-        C_c, C_f = model(row, col, poses_bound, K_inv)
-        loss = model.ray_loss(C_c, C_f, C_true)
-        loss.backward()
+        if hasattr(model, "train_step"):  # forward + loss + backward in ONE library call (same kernels, same bits)
+            C_c, C_f, loss = model.train_step(row, col, poses_bound, K_inv, C_true)
+        else:
+            C_c, C_f = model(row, col, poses_bound, K_inv)
+            loss = model.ray_loss(C_c, C_f, C_true)
+            loss.backward()
     finally:
         model.ray0_near_far, model.grad_bucket = prev_ray0, prev_bucket
     if world > 1 or (dist.is_available() and dist.is_initialized()):

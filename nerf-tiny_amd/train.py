@@ -245,9 +245,8 @@ class NeRFRunner:
                     _, _, loss = par.train_step_local(self.model, self.bucket, row, col, poses_bound, self.K_inv, pix_val, batch[5],
                                                       self.world, self.group)
                 else:
-                    C_coarse, C_fine = self.model(row, col, poses_bound, self.K_inv)
-                    loss = self.model.ray_loss(C_coarse, C_fine, pix_val)
-                    loss.backward()
+                    # nerf.py:470-473 (forward, ray_loss, backward) as ONE library call: same kernels, no interpreter between them
+                    _, _, loss = self.model.train_step(row, col, poses_bound, self.K_inv, pix_val)
                 self.optimizer.step()
                 self.scheduler.step()
                 if (it + 1) % self.log_every == 0:  # the only host sync of the loop

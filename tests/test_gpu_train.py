@@ -370,3 +370,46 @@ def test_plain_loop_in_bucket_mode_needs_no_consume_call(oracle, pkg, dev):
     with pytest.raises(RuntimeError, match="second backward"):
         m.ray_loss(Cc, Cf, C_true.to(dev)).backward()
     m.grad_bucket.consume()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_fused_train_step_equals_autograd_path(oracle, pkg, dev, bf16):
+    """nerf_hip_train_step (ABI 5) / NeRFModel.train_step: the reference's three calls of an iteration (nerf.py:470-473: forward, ray_loss,
+    loss.backward()) enqueued by ONE library call.  Same kernels in the same order: colours, loss and all 24 gradients bit-identical to the
+    autograd path, with fresh gradient tensors and with a GradBucket; a wrong batch size raises; what NeRFRunner.trainer calls."""
+    Bs = 96
+    row, col, pb, K, C_true = oracle.lego_inputs(Bs, seed=17)
+    w = oracle.make_weights(9, sharp=True)
+
+    def model():
+        m = pkg.NeRFModel(64, 128, Bs)
+        m.load_state_dict(w)
+        m = m.to(dev)
+        m.bf16_mlp = bf16
+        return m
+
+    a = model()
+    Cc, Cf = a(row, col, pb, K)
+    la = a.ray_loss(Cc, Cf, C_true.to(dev))
+    la.backward()
+    for use_bucket in (False, True):
+        b = model()
+        if use_bucket:
+            b.grad_bucket = pkg.parallel.GradBucket(b.network.parameters())
+        Bc, Bf, lb = b.train_step(row, col, pb, K, C_true)
+        assert torch.equal(Bc, Cc.detach()) and torch.equal(Bf, Cf.detach()) and float(lb) == float(la.detach())
+        for p, q in zip(a.network.parameters(), b.network.parameters()):
+            assert torch.equal(p.grad, q.grad)
+        if use_bucket:
+            assert b.grad_bucket.pending and all(q.grad.data_ptr() == v.data_ptr() for q, v in zip(b.network.parameters(), b.grad_bucket.views))
+            with pytest.raises(RuntimeError, match="second backward"):
+                b.train_step(row, col, pb, K, C_true)
+            b.grad_bucket.consume()
+        # a second step overwrites (zero_grad(set_to_none) + backward semantics), it does not accumulate
+        b.train_step(row, col, pb, K, C_true)
+        for p, q in zip(a.network.parameters(), b.network.parameters()):
+            assert torch.equal(p.grad, q.grad)
+        if use_bucket:
+            b.grad_bucket.consume()
+    with pytest.raises(ValueError):
+        a.train_step(row[:10], col[:10], pb[:10], K, C_true[:10])
