@@ -5,6 +5,7 @@
 #include "bf16_common.h"
 #include "field_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -23,6 +24,12 @@ constexpr int BF_D = 6;         // fragment reads in flight per wave (<= BF_CHUN
 constexpr int BF_EPI_POS = 2;   // k-step of the next tile at which a finished accumulator is consumed
 constexpr int BF_WG = 512;      // 8 waves x 32 samples
 constexpr int BF_LDS_BYTES = BF_BIAS_BYTES + BF_NS * BF_CHUNK * BF_FRAG_BYTES;
+constexpr int BF_SMALL_MAX_WGS = 256;  // the training kernels run 4-wave workgroups (128 samples) up to this many of them: one per CU
+// NERF_BF16_4WAVE=0: the training kernels keep 8-wave workgroups for small passes too (A/B measurements only)
+inline bool bf16_four_waves_disabled() {
+  static const bool off = [] { const char* e = getenv("NERF_BF16_4WAVE"); return e && atoi(e) == 0; }();
+  return off;
+}
 static_assert(BF_D <= BF_CHUNK - BF_SYNC_POS, "a prefetched fragment must not lie in an unpublished chunk");
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {  // two fp32 -> two bf16 (RNE), a in the low half

@@ -52,10 +52,13 @@ struct BwdStream {
   __device__ static constexpr int stores_before(int idx) { return tab.cum[idx]; }
 };
 
-template <bool FINE>
-__global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs a) {
+template <class Base> struct FourWavesB : Base { static constexpr int PW = 4; };
+
+// WAVES = 4 (128 samples per workgroup, one wave per SIMD): small passes, so that every CU gets a workgroup (field_fwd_bf16.hip)
+template <bool FINE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_field_bwd_bf16(const FieldBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  using S = BwdStream<FINE>;
+  using S = std::conditional_t<WAVES == 4, FourWavesB<BwdStream<FINE>>, BwdStream<FINE>>;
   BfCtx c;
   c.wimg = a.wbf;
   c.lds = lds;
@@ -63,13 +66,13 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
   c.lane = threadIdx.x & 63;
   c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = c.lane, j = lane & 31, h = lane >> 5;
-  const int m = blockIdx.x * (BF_WG / 2) + c.wv * 32 + j;
+  const int m = blockIdx.x * (32 * WAVES) + c.wv * 32 + j;
   const bool valid = m < a.M;
   const int mc = valid ? m : a.M - 1;
 #ifdef NERF_TIMING_SAVE_ALIAS  // (timing experiments only: masks read from / gradients written to the same few KiB)
   const int wb = c.wv;
 #else
-  const int wb = a.wb0 + blockIdx.x * (BF_WG / 64) + c.wv;
+  const int wb = a.wb0 + blockIdx.x * WAVES + c.wv;
 #endif
 
   // ---- ordinary loads first: upstream gradients -> dz (colour head, pre-sigmoid) and dspre (sigma head, pre-abs)
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_bwd_bf16(const FieldBwdArgs 
     // loads and the 16 sincos below cannot be hoisted over it)
     const int lane_e = (int)lane_id_here();
     const int h_e = lane_e >> 5;
-    const int m_e = blockIdx.x * (BF_WG / 2) + c.wv * 32 + (lane_e & 31);
+    const int m_e = blockIdx.x * (32 * WAVES) + c.wv * 32 + (lane_e & 31);
     const bool valid_e = m_e < a.M;
     const int mcl = valid_e ? m_e : a.M - 1;
     const int ray = mcl / a.N;
@@ -233,12 +236,20 @@ hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, const float* fold, u
 
 hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st) {
   static std::atomic<unsigned long long> opted{0};
-  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_bwd_bf16<false>), reinterpret_cast<const void*>(&k_field_bwd_bf16<true>)}, BB_LDS_BYTES)) return e;
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_bwd_bf16<false, 8>), reinterpret_cast<const void*>(&k_field_bwd_bf16<true, 8>),
+                                                reinterpret_cast<const void*>(&k_field_bwd_bf16<false, 4>), reinterpret_cast<const void*>(&k_field_bwd_bf16<true, 4>)}, BB_LDS_BYTES)) return e;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
+  if (2 * wgs <= BF_SMALL_MAX_WGS && !bf16_four_waves_disabled()) {  // a small pass: 4-wave workgroups, so that every CU gets one
+    if (fine)
+      hipLaunchKernelGGL((k_field_bwd_bf16<true, 4>), dim3(2 * wgs), dim3(256), BB_LDS_BYTES, st, a);
+    else
+      hipLaunchKernelGGL((k_field_bwd_bf16<false, 4>), dim3(2 * wgs), dim3(256), BB_LDS_BYTES, st, a);
+    return hipGetLastError();
+  }
   if (fine)
-    hipLaunchKernelGGL((k_field_bwd_bf16<true>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_bwd_bf16<true, 8>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a);
   else
-    hipLaunchKernelGGL((k_field_bwd_bf16<false>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_bwd_bf16<false, 8>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 

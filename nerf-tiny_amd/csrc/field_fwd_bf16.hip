@@ -55,8 +55,13 @@ struct FwdStream {
   __device__ static constexpr int stores_before(int idx) { return SAVE ? kFwdStoreTable.cum[idx] : 0; }
 };
 
-template <bool SAVE>
-__global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) {
+// A stream description for a 4-wave workgroup: the 16 pieces of a chunk over 4 waves (bf16_stream.h BfPW)
+template <class Base> struct FourWaves : Base { static constexpr int PW = 4; };
+
+// WAVES = 8: 256 samples per workgroup, two waves per SIMD.  WAVES = 4 (128 samples, one wave per SIMD) is what a SMALL pass gets: the
+// coarse pass of a 512-ray batch is 128 workgroups of 256 samples -- half of the CUs idle -- or 256 of 128 (as field_fwd_bf16x.hip does).
+template <bool SAVE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16(const FieldArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   BfCtx c;
   c.wimg = a.wbf;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   c.lane = threadIdx.x & 63;
   c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = c.lane, j = lane & 31, h = lane >> 5;
-  const int m = blockIdx.x * (BF_WG / 2) + c.wv * 32 + j;
+  const int m = blockIdx.x * (32 * WAVES) + c.wv * 32 + j;
   const bool valid = m < a.M;
   const int mc = valid ? m : a.M - 1;
   const int ray = mc / a.N;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p[i]), "+v"(dw[i]));  // values are in registers from here on
 
   // ---- start the weight stream: bias block and chunks 0 .. BF_NS-2
-  using S = FwdStream<SAVE>;
+  using S = std::conditional_t<WAVES == 4, FourWaves<FwdStream<SAVE>>, FwdStream<SAVE>>;
   bf_stream_start<S>(c);
 
   // ---- positional encodings straight into B-operand registers (fp32 values as in the fp32 path, rounded to bf16):
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
 #ifdef NERF_TIMING_SAVE_ALIAS  // (timing experiments only: every save lands in the same few KiB -> the stores issue, HBM sees none)
   const int wb = c.wv;
 #else
-  const int wb = a.wb0 + blockIdx.x * (BF_WG / 64) + c.wv;
+  const int wb = a.wb0 + blockIdx.x * WAVES + c.wv;
 #endif
   unsigned mw[4];  // (every word is assigned by its even tile before the odd one ORs into it; words 2, 3 of a 4-tile layer are written as 0)
   // `lane16` = this lane's byte offset inside a piece.  The layers' epilogues pass a value produced AT their program point (mbcnt): left
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(BF_WG, 1) void k_field_fwd_bf16(const FieldArgs a) 
   bf_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd, Y, relu_to(X, BS_C, 8, 4), sig_epi);
   // (the sample index is re-derived from the lane id behind the stream -- mbcnt, not threadIdx: nothing to keep alive or spill)
   const int lane_e = (int)lane_id_here();
-  const int m_e = blockIdx.x * (BF_WG / 2) + c.wv * 32 + (lane_e & 31);
+  const int m_e = blockIdx.x * (32 * WAVES) + c.wv * 32 + (lane_e & 31);
   const bool out_e = m_e < a.M && lane_e < 32;
   if (out_e) {
     a.sigma[m_e] = fabsf(spre);
@@ -266,12 +271,20 @@ hipError_t launch_pack_bias_block_bf16(const Weights24& w, const float* fold, un
 
 hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st) {
   static std::atomic<unsigned long long> opted{0};  // >64 KiB of dynamic LDS needs an opt-in, once per device and kernel
-  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16<false>), reinterpret_cast<const void*>(&k_field_fwd_bf16<true>)}, BFW_LDS_BYTES)) return e;
-  const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16<false, 8>), reinterpret_cast<const void*>(&k_field_fwd_bf16<true, 8>),
+                                                reinterpret_cast<const void*>(&k_field_fwd_bf16<false, 4>), reinterpret_cast<const void*>(&k_field_fwd_bf16<true, 4>)}, BFW_LDS_BYTES)) return e;
+  const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);  // 256-sample workgroups: the pass's wave blocks are whole ones of these (api.hip wave_blocks)
+  if (2 * wgs <= BF_SMALL_MAX_WGS && !bf16_four_waves_disabled()) {  // a small pass: 4-wave workgroups, so that every CU gets one
+    if (save)
+      hipLaunchKernelGGL((k_field_fwd_bf16<true, 4>), dim3(2 * wgs), dim3(256), BFW_LDS_BYTES, st, a);
+    else
+      hipLaunchKernelGGL((k_field_fwd_bf16<false, 4>), dim3(2 * wgs), dim3(256), BFW_LDS_BYTES, st, a);
+    return hipGetLastError();
+  }
   if (save)
-    hipLaunchKernelGGL((k_field_fwd_bf16<true>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_fwd_bf16<true, 8>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a);
   else
-    hipLaunchKernelGGL((k_field_fwd_bf16<false>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_fwd_bf16<false, 8>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 

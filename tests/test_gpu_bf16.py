@@ -378,7 +378,7 @@ def _variant(tmp_path, name, env_extra, B=96):
 
     from conftest import ROOT
 
-    env = {k: v for k, v in os.environ.items() if k not in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16")}
+    env = {k: v for k, v in os.environ.items() if k not in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16", "NERF_BF16_4WAVE", "NERF_DW_BF16_SMALLGROUP")}
     env.update(env_extra)
     out = str(tmp_path / (name + ".pt"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "bf16_variant_dump.py"), out, str(B)], capture_output=True, text=True,
@@ -437,3 +437,18 @@ def test_pair_kernel_equals_separate_launches(tmp_path):
         assert one["S_fault"] is True and sep["S_fault"] is True
         assert one["S_fault_after_healthy"] is False and sep["S_fault_after_healthy"] is False
         assert one["sticky"] & 2 == 0
+
+
+@pytest.mark.timeout(900)
+def test_four_wave_training_workgroups_equal_eight_wave_ones(tmp_path):
+    """field_fwd_bf16.hip / field_bwd_bf16.hip: a SMALL pass runs 4-wave workgroups (128 samples, one wave per SIMD) so that every CU gets one
+    (the coarse pass of a 512-ray batch is 128 workgroups of 256 samples); NERF_BF16_4WAVE=0 keeps the 8-wave ones.  The same waves on the
+    same wave blocks with the same fragment stream: outputs, saved activations and therefore every gradient bit for bit."""
+    for B in (96, 333):
+        four = _variant(tmp_path, f"w4_{B}", {"NERF_DW_BF16_MULTI": "1"}, B)
+        eight = _variant(tmp_path, f"w8_{B}", {"NERF_BF16_4WAVE": "0", "NERF_DW_BF16_MULTI": "1"}, B)
+        for k in ("Cc", "Cf", "train_packed_bf"):
+            assert torch.equal(four[k], eight[k]), (B, k)
+        assert four["loss"] == eight["loss"]
+        for i, (a, b) in enumerate(zip(four["grads"], eight["grads"])):
+            assert torch.equal(a, b), (B, i)

@@ -79,7 +79,7 @@ def main():
     st = C.c_uint32(0)
     _abi.check(_abi.lib().nerf_hip_read_status_sticky(ws.data_ptr(), ws.numel(), C.byref(st), 0, torch.cuda.current_stream(dev).cuda_stream))
     res["sticky"] = int(st.value)
-    res["env"] = {k: os.environ.get(k) for k in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16")}
+    res["env"] = {k: os.environ.get(k) for k in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16", "NERF_BF16_4WAVE")}
     torch.save(res, out)
     print("DUMP-OK", res["env"], flush=True)
 
