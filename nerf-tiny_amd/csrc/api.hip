@@ -79,6 +79,13 @@ int dw_bf16_small_group() {
   static const int v = [] { const char* e = getenv("NERF_DW_BF16_SMALLGROUP"); return e ? atoi(e) : DW_BF16_SMALL_GROUP_DEFAULT; }();
   return v;
 }
+// bf16 training: the per-ray stages as epilogues / prologues of the field launches up to this many rays (one round of fine-pass workgroups:
+// the stage runs on a quarter of a workgroup's waves).  NERF_FUSE_RAYS=0 / 1 overrides the choice (A/B measurements only)
+constexpr int FUSE_RAYS_BF16_MAX_RAYS = 512;
+bool fuse_rays_bf16(int B) {
+  static const int forced = [] { const char* e = getenv("NERF_FUSE_RAYS"); return e ? atoi(e) : -1; }();
+  return forced >= 0 ? forced != 0 : B <= FUSE_RAYS_BF16_MAX_RAYS;
+}
 constexpr int DW_BF16_MULTI_MAX_WB = 5120;  // 853 rays x (64 + 128); measured: 400 rays -25 %, 512 -18 %, 1024 +-0, 2048 +10 %, 4096 +30 %
 bool dw_bf16_multi(int wb_tot) {
   static const int forced = [] { const char* e = getenv("NERF_DW_BF16_MULTI"); return e ? atoi(e) : -1; }();
@@ -397,9 +404,12 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
     HIP_TRY(launch_render_pair_bf16x(pa, st));
     return NERF_HIP_OK;
   }
+  // SMALL bf16 TRAINING batches at the shipped sample counts: k_coarse / k_merge ride as epilogues of the field launches (kernels.h FwdFuse)
+  const bool fuse_rays = bf16 && save && Nc == 64 && Nf == 128 && fuse_rays_bf16(B);
+  FwdFuse ff;
+  memset(&ff, 0, sizeof(ff));
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  auto field = [&](const FieldArgs& f) { return split ? launch_field_fwd_split(f, st) : bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
-  { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st, &pc); HIP_TRY(field(fa)); }
+  auto field = [&](const FieldArgs& f) { return split ? launch_field_fwd_split(f, st) : bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st, ff.mode ? &ff : nullptr) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
 
   CoarseArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -411,7 +421,14 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ca.w_c = at<float>(ws, L.w_c); ca.C_coarse = C_coarse; ca.t_f = at<float>(ws, L.t_f);
   ca.status = at<uint32_t>(ws, L.status);
   ca.sticky = at<uint32_t>(ws, L.status) + STATUS_STICKY_WORD;
-  { ProfScope ps(NERF_HIP_K_COARSE, st, &pc); HIP_TRY(launch_coarse(ca, st)); }
+  if (fuse_rays) {
+    ff.mode = 1; ff.c = ca;
+    { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st, &pc); HIP_TRY(field(fa)); }
+    ff.mode = 0;
+  } else {
+    { ProfScope ps(NERF_HIP_K_FIELD_COARSE, st, &pc); HIP_TRY(field(fa)); }
+    { ProfScope ps(NERF_HIP_K_COARSE, st, &pc); HIP_TRY(launch_coarse(ca, st)); }
+  }
 
   // fine pass (nerf.py:299), same network (quirk Q10)
   fa.t = at<float>(ws, L.t_f);
@@ -419,8 +436,6 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   fa.sigma = at<float>(ws, L.sig_f);
   fa.N = Nf; fa.M = B * Nf;
   if (save) { fa.row0 = B * Nc; fa.tile0 = tiles_c; fa.wb0 = (int)wave_blocks(B, Nc); }
-  { ProfScope ps(NERF_HIP_K_FIELD_FINE, st, &pc); HIP_TRY(field(fa)); }
-
   MergeArgs ma;
   memset(&ma, 0, sizeof(ma));
   ma.t_c = at<float>(ws, L.t_c); ma.t_f = at<float>(ws, L.t_f);
@@ -430,7 +445,13 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ma.last = last_delta;
   if (save) { ma.bundle = at<float>(ws, L.bundle); ma.w = at<float>(ws, L.w_m); ma.perm = at<uint16_t>(ws, L.perm); }
   ma.C_fine = C_fine;
-  { ProfScope ps(NERF_HIP_K_MERGE, st, &pc); HIP_TRY(launch_merge(ma, st)); }
+  if (fuse_rays) {
+    ff.mode = 2; ff.m = ma;
+    { ProfScope ps(NERF_HIP_K_FIELD_FINE, st, &pc); HIP_TRY(field(fa)); }
+  } else {
+    { ProfScope ps(NERF_HIP_K_FIELD_FINE, st, &pc); HIP_TRY(field(fa)); }
+    { ProfScope ps(NERF_HIP_K_MERGE, st, &pc); HIP_TRY(launch_merge(ma, st)); }
+  }
   return NERF_HIP_OK;
 }
 
@@ -513,7 +534,11 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
   mb.B = B; mb.Nc = Nc; mb.Nf = Nf; mb.last = last_delta;
   mb.drgb_c = at<float>(ws, L.drgb_c); mb.dsig_c = at<float>(ws, L.dsig_c);
   mb.drgb_f = at<float>(ws, L.drgb_f); mb.dsig_f = at<float>(ws, L.dsig_f); mb.dt_f = at<float>(ws, L.dt_f);
-  { ProfScope ps(NERF_HIP_K_BWD_MERGE, st, &pc); HIP_TRY(launch_merge_bwd(mb, st)); }
+  // SMALL bf16 batches: the per-ray backward stages ride as prologues of the chain launches (kernels.h BwdFuse)
+  const bool fuse_rays = bf16 && Nc == 64 && Nf == 128 && fuse_rays_bf16(B);
+  BwdFuse bz;
+  memset(&bz, 0, sizeof(bz));
+  if (!fuse_rays) { ProfScope ps(NERF_HIP_K_BWD_MERGE, st, &pc); HIP_TRY(launch_merge_bwd(mb, st)); }
 
   // 2. fine-pass field backward (dX chain incl. d loss / d t_fine)
   FieldBwdArgs fb;
@@ -535,8 +560,10 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
   fb.drgb = at<float>(ws, L.drgb_f); fb.dsig = at<float>(ws, L.dsig_f); fb.dt = at<float>(ws, L.dt_f);
   fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf; fb.wb0 = wb_c;
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  auto chain = [&](const FieldBwdArgs& f, bool fine) { return bf16 ? launch_field_bwd_bf16(f, fine, st) : tile_kernel ? launch_field_bwd(f, fine, st) : launch_field_bwd_reg(f, fine, st); };
+  auto chain = [&](const FieldBwdArgs& f, bool fine) { return bf16 ? launch_field_bwd_bf16(f, fine, st, bz.mode ? &bz : nullptr) : tile_kernel ? launch_field_bwd(f, fine, st) : launch_field_bwd_reg(f, fine, st); };
+  if (fuse_rays) { bz.mode = 1; bz.m = mb; }
   { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st, &pc); HIP_TRY(chain(fb, true)); }
+  bz.mode = 0;
 
   // 3. resampling + coarse composite backward (nerf.py:225-261, 263-281)
   CoarseBwdArgs cb;
@@ -547,7 +574,8 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
   cb.B = B; cb.Nc = Nc; cb.Nf = Nf;
   if (ray0_near_far) { cb.ray0_override = 1; cb.near0 = ray0_near_far[0]; cb.far0 = ray0_near_far[1]; }
   cb.drgb_c = at<float>(ws, L.drgb_c); cb.dsig_c = at<float>(ws, L.dsig_c);
-  { ProfScope ps(NERF_HIP_K_BWD_COARSE, st, &pc); HIP_TRY(launch_coarse_bwd(cb, st)); }
+  if (fuse_rays) { bz.mode = 2; bz.c = cb; }
+  else { ProfScope ps(NERF_HIP_K_BWD_COARSE, st, &pc); HIP_TRY(launch_coarse_bwd(cb, st)); }
 
   // 4. coarse-pass field backward
   fb.t = at<float>(ws, L.t_c); fb.rgb = at<float>(ws, L.rgb_c);

@@ -12,6 +12,9 @@
 // Gradients are rounded to bf16 where they enter an MFMA (standard mixed precision); sums stay fp32.
 #include "bf16_stream.h"
 #include "bf16_weights.h"
+#include "ray_parts_bwd.h"
+
+#include <string.h>
 
 namespace nerf {
 
@@ -56,7 +59,7 @@ template <class Base> struct FourWavesB : Base { static constexpr int PW = 4; };
 
 // WAVES = 4 (128 samples per workgroup, one wave per SIMD): small passes, so that every CU gets a workgroup (field_fwd_bf16.hip)
 template <bool FINE, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_field_bwd_bf16(const FieldBwdArgs a) {
+__global__ __launch_bounds__(64 * WAVES, 1) void k_field_bwd_bf16(const FieldBwdArgs a, const BwdFuse fz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   using S = std::conditional_t<WAVES == 4, FourWavesB<BwdStream<FINE>>, BwdStream<FINE>>;
   BfCtx c;
@@ -75,6 +78,30 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_bwd_bf16(const FieldBwd
   const int wb = a.wb0 + blockIdx.x * WAVES + c.wv;
 #endif
 
+  // ---- SMALL batches (kernels.h BwdFuse): the per-ray backward stage that would be the launch in FRONT of this one runs here first, on the
+  // workgroup's own rays (32 WAVES samples = 1 or 2 fine rays, 2 or 4 coarse rays); its outputs (d rgb, d sigma, d t of the samples) go to
+  // the same global buffers and are read back below, behind a barrier (stores complete; same CU, lines nobody has read in this launch)
+  if (fz.mode != 0) {  // (kernel argument: uniform)
+    float* const scr = reinterpret_cast<float*>(lds);  // nothing has been brought to LDS yet
+    auto wave_fence = [] {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    };
+    if (FINE) {
+      if (c.wv < WAVES / 4) {
+        const int ray = blockIdx.x * (WAVES / 4) + c.wv;
+        if (ray < fz.m.B) merge_bwd_ray(fz.m, ray, lane, scr + c.wv * 4 * 192, wave_fence);
+      }
+    } else {
+      if (c.wv < WAVES / 2) {
+        const int ray_raw = blockIdx.x * (WAVES / 2) + c.wv;
+        const bool live = ray_raw < fz.c.B;
+        float* w = scr + c.wv * (5 * 64 + 64);
+        coarse_bwd_ray(fz.c, live ? ray_raw : fz.c.B - 1, live, lane, w, reinterpret_cast<uint16_t*>(w + 5 * 64), wave_fence);
+      }
+    }
+    __syncthreads();
+  }
   // ---- ordinary loads first: upstream gradients -> dz (colour head, pre-sigmoid) and dspre (sigma head, pre-abs)
   float dz[3];
 #pragma unroll
@@ -234,22 +261,25 @@ hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, const float* fold, u
   return hipGetLastError();
 }
 
-hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st) {
+hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st, const BwdFuse* fuse) {
+  BwdFuse fz;
+  if (fuse) fz = *fuse; else memset(&fz, 0, sizeof(fz));
+  if (fz.mode && (a.N != (fine ? 128 : 64) || (fz.mode == 1) != fine)) return hipErrorInvalidValue;  // whole rays per workgroup only at the shipped sample counts
   static std::atomic<unsigned long long> opted{0};
   if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_bwd_bf16<false, 8>), reinterpret_cast<const void*>(&k_field_bwd_bf16<true, 8>),
                                                 reinterpret_cast<const void*>(&k_field_bwd_bf16<false, 4>), reinterpret_cast<const void*>(&k_field_bwd_bf16<true, 4>)}, BB_LDS_BYTES)) return e;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);
   if (2 * wgs <= BF_SMALL_MAX_WGS && !bf16_four_waves_disabled()) {  // a small pass: 4-wave workgroups, so that every CU gets one
     if (fine)
-      hipLaunchKernelGGL((k_field_bwd_bf16<true, 4>), dim3(2 * wgs), dim3(256), BB_LDS_BYTES, st, a);
+      hipLaunchKernelGGL((k_field_bwd_bf16<true, 4>), dim3(2 * wgs), dim3(256), BB_LDS_BYTES, st, a, fz);
     else
-      hipLaunchKernelGGL((k_field_bwd_bf16<false, 4>), dim3(2 * wgs), dim3(256), BB_LDS_BYTES, st, a);
+      hipLaunchKernelGGL((k_field_bwd_bf16<false, 4>), dim3(2 * wgs), dim3(256), BB_LDS_BYTES, st, a, fz);
     return hipGetLastError();
   }
   if (fine)
-    hipLaunchKernelGGL((k_field_bwd_bf16<true, 8>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_bwd_bf16<true, 8>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a, fz);
   else
-    hipLaunchKernelGGL((k_field_bwd_bf16<false, 8>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_bwd_bf16<false, 8>), dim3(wgs), dim3(BF_WG), BB_LDS_BYTES, st, a, fz);
   return hipGetLastError();
 }
 

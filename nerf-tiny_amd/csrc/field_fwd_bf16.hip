@@ -18,7 +18,10 @@
 //     0..2 of a 32-row tile), 24 MFMAs instead of ~400 VALU instructions;
 //   * point_info (no activation) is folded into dir_info's feature columns (bf16_common.h): 128 MFMAs per wave block less.
 #include "bf16_stream.h"
+
+#include <string.h>
 #include "bf16_weights.h"
+#include "ray_parts.h"
 
 namespace nerf {
 
@@ -61,7 +64,7 @@ template <class Base> struct FourWaves : Base { static constexpr int PW = 4; };
 // WAVES = 8: 256 samples per workgroup, two waves per SIMD.  WAVES = 4 (128 samples, one wave per SIMD) is what a SMALL pass gets: the
 // coarse pass of a 512-ray batch is 128 workgroups of 256 samples -- half of the CUs idle -- or 256 of 128 (as field_fwd_bf16x.hip does).
 template <bool SAVE, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16(const FieldArgs a) {
+__global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16(const FieldArgs a, const FwdFuse fz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   BfCtx c;
   c.wimg = a.wbf;
@@ -232,6 +235,34 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16(const FieldArg
     a.rgb[(size_t)m_e * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
     a.rgb[(size_t)m_e * 3 + 2] = 1.0f / (1.0f + expf(-acc[1][2]));
   }
+  // ---- SMALL batches (kernels.h FwdFuse): the per-ray stage that would be the next launch runs HERE, on the workgroup's own rays -- its
+  // samples are whole rays (32 WAVES = 2 or 4 coarse rays of 64, 1 or 2 fine rays of 128).  Behind a barrier: every wave's sigma / rgb
+  // stores have completed (same CU: write-through L1, lines nobody has read in this launch) and the ring is free to be scratch.
+  if constexpr (SAVE) {
+    if (fz.mode != 0) {  // (kernel argument: uniform)
+      __syncthreads();
+      float* const scr = reinterpret_cast<float*>(lds + BF_BIAS_BYTES);
+      const int lane_f = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      auto wave_fence = [] {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      };
+      if (fz.mode == 1) {        // k_coarse: one ray per wave, WAVES / 2 rays
+        if (c.wv < WAVES / 2) {
+          float* w = scr + c.wv * 3 * 64;
+          coarse_ray_stage(fz.c, blockIdx.x * (WAVES / 2) + c.wv, lane_f, w, w + 64, w + 128, wave_fence);
+        }
+      } else {                   // k_merge<true>: WAVES / 4 rays
+        if (c.wv < WAVES / 4) {
+          const int ray = blockIdx.x * (WAVES / 4) + c.wv;
+          if (ray < fz.m.B) {
+            float* val = scr + c.wv * (5 * 256 + 5 * 128);  // [5][256] floats + [5][256] u16
+            merge_ray_stage<true>(fz.m, ray, lane_f, val, reinterpret_cast<uint16_t*>(val + 5 * 256), wave_fence);
+          }
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -269,22 +300,25 @@ hipError_t launch_pack_bias_block_bf16(const Weights24& w, const float* fold, un
   return hipGetLastError();
 }
 
-hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st) {
+hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st, const FwdFuse* fuse) {
+  FwdFuse fz;
+  if (fuse) fz = *fuse; else memset(&fz, 0, sizeof(fz));
+  if (fz.mode && (!save || a.N != (fz.mode == 1 ? 64 : 128))) return hipErrorInvalidValue;  // whole rays per workgroup only at the shipped sample counts
   static std::atomic<unsigned long long> opted{0};  // >64 KiB of dynamic LDS needs an opt-in, once per device and kernel
   if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_bf16<false, 8>), reinterpret_cast<const void*>(&k_field_fwd_bf16<true, 8>),
                                                 reinterpret_cast<const void*>(&k_field_fwd_bf16<false, 4>), reinterpret_cast<const void*>(&k_field_fwd_bf16<true, 4>)}, BFW_LDS_BYTES)) return e;
   const int wgs = (a.M + BF_WG / 2 - 1) / (BF_WG / 2);  // 256-sample workgroups: the pass's wave blocks are whole ones of these (api.hip wave_blocks)
   if (2 * wgs <= BF_SMALL_MAX_WGS && !bf16_four_waves_disabled()) {  // a small pass: 4-wave workgroups, so that every CU gets one
     if (save)
-      hipLaunchKernelGGL((k_field_fwd_bf16<true, 4>), dim3(2 * wgs), dim3(256), BFW_LDS_BYTES, st, a);
+      hipLaunchKernelGGL((k_field_fwd_bf16<true, 4>), dim3(2 * wgs), dim3(256), BFW_LDS_BYTES, st, a, fz);
     else
-      hipLaunchKernelGGL((k_field_fwd_bf16<false, 4>), dim3(2 * wgs), dim3(256), BFW_LDS_BYTES, st, a);
+      hipLaunchKernelGGL((k_field_fwd_bf16<false, 4>), dim3(2 * wgs), dim3(256), BFW_LDS_BYTES, st, a, fz);
     return hipGetLastError();
   }
   if (save)
-    hipLaunchKernelGGL((k_field_fwd_bf16<true, 8>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_fwd_bf16<true, 8>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a, fz);
   else
-    hipLaunchKernelGGL((k_field_fwd_bf16<false, 8>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_field_fwd_bf16<false, 8>), dim3(wgs), dim3(BF_WG), BFW_LDS_BYTES, st, a, fz);
   return hipGetLastError();
 }
 

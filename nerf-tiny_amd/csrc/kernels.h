@@ -105,11 +105,19 @@ struct MergeArgs {
   float* C_fine;   // [B][3]
 };
 
+// SMALL bf16 training batches (Nc = 64, Nf = 128): the per-ray stages ride in the field kernels instead of launches of their own --
+// k_coarse / k_merge as EPILOGUES of the coarse / fine forward pass, k_merge_bwd / k_coarse_bwd as PROLOGUES of the fine / coarse chain
+// (a workgroup's samples are whole rays: 128 samples = 2 coarse rays or 1 fine ray, 256 = 4 or 2); mode 0 = none
+struct FwdFuse {
+  int mode;      // 1: coarse composite + resampling behind the coarse pass, 2: merge + sorts + composite behind the fine pass
+  CoarseArgs c;
+  MergeArgs m;
+};
 hipError_t launch_pack_weights(const Weights24& w, float* fold, float4* out, int nseg, hipStream_t st);  // fold: FOLD_FLOATS scratch (launch_fold_weights runs first)
 hipError_t launch_fold_weights(const Weights24& w, float* fold, hipStream_t st);  // fold: FOLD_FLOATS (b_fold, then W_fold): bf16-MLP variant
 hipError_t launch_field_fwd(const FieldArgs& a, bool save, hipStream_t st);
 hipError_t launch_field_fwd_reg(const FieldArgs& a, bool save, hipStream_t st);
-hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st);
+hipError_t launch_field_fwd_bf16(const FieldArgs& a, bool save, hipStream_t st, const FwdFuse* fuse = nullptr);
 // the bf16 packers read the fp32 fold (launch_fold_weights, same stream, before them)
 hipError_t launch_pack_weights_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 hipError_t launch_pack_bias_block_bf16(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
@@ -256,6 +264,12 @@ struct CoarseBwdArgs {
   float *drgb_c, *dsig_c;  // in: merge contribution, out: total
 };
 
+struct BwdFuse {
+  int mode;      // 1: merged-composite backward in front of the fine chain, 2: resampling + coarse-composite backward in front of the coarse chain
+  MergeBwdArgs m;
+  CoarseBwdArgs c;
+};
+
 struct SmallGradArgs {
   const float* save;       // saves base
   const float* G;          // grads base
@@ -273,7 +287,7 @@ struct SmallGradArgs {
 
 hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st);
 hipError_t launch_field_bwd_reg(const FieldBwdArgs& a, bool fine, hipStream_t st);
-hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st);
+hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st, const BwdFuse* fuse = nullptr);
 hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 size_t dw_bf16_slab_floats();
 hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned char* X1, int x1_ks, const unsigned char* X2, int x2_ks,

@@ -35,32 +35,7 @@ __global__ __launch_bounds__(256) void k_coarse(const CoarseArgs a) {
   __shared__ float s_cdf[4][MAXN];
   __shared__ float s_t[4][MAXN];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ray_raw = blockIdx.x * 4 + wv;
-  const bool live = ray_raw < a.B;
-  const int ray = live ? ray_raw : a.B - 1;
-  float near, far;
-  if (a.rayf) {
-    near = a.rayf[(size_t)ray * RAYF + RF_NEAR];
-    far = a.rayf[(size_t)ray * RAYF + RF_FAR];
-  } else {
-    near = a.near_far[2 * ray];
-    far = a.near_far[2 * ray + 1];
-  }
-  // spacing of RAY 0 used for every ray (quirk Q6, nerf.py:233): t[0][1] - t[0][0]
-  float delta0 = a.delta0;
-  if (a.delta0_mode == 0) {
-    const float n0 = a.ray0_override ? a.near0 : a.rayf[RF_NEAR];
-    const float f0 = a.ray0_override ? a.far0 : a.rayf[RF_FAR];
-    delta0 = ray0_spacing(n0, f0, a.Nc);
-  }
-  const size_t g0 = (size_t)ray * a.Nc;
-  float lo, hi;
-  coarse_ray_weights(a.sigma + g0, a.rgb + g0 * 3, a.t_c + g0, near, far, a.Nc, lane, s_w[wv], s_cdf[wv], s_t[wv],
-                     (live && a.w_c) ? a.w_c + g0 : nullptr, (live && a.C_coarse) ? a.C_coarse + (size_t)ray * 3 : nullptr, lo, hi);
-  __syncthreads();
-  const bool bad = coarse_ray_resample(s_w[wv], s_cdf[wv], s_t[wv], lo, hi, delta0, a.Nc, a.Nf, lane, live ? a.t_f + (size_t)ray * a.Nf : nullptr);
-  if (live && bad && a.status) atomicOr(a.status, 1u);
-  if (live && bad && a.sticky) atomicOr(a.sticky, 1u);
+  coarse_ray_stage(a, blockIdx.x * 4 + wv, lane, s_w[wv], s_cdf[wv], s_t[wv], [] { __syncthreads(); });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -73,34 +48,9 @@ __global__ __launch_bounds__(256) void k_coarse(const CoarseArgs a) {
 template <bool WITH_IDX>  // WITH_IDX: carry the original index (stable order + permutation for backward)
 __global__ __launch_bounds__(64) void k_merge(const MergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int P = a.P, N = a.Nc + a.Nf;
-  float* val = reinterpret_cast<float*>(smem_raw);                  // [5][P]
-  uint16_t* idx = reinterpret_cast<uint16_t*>(val + 5 * (size_t)P);  // [5][P]
-  const int lane = threadIdx.x;
-  const int ray = blockIdx.x;
-  // load: channel 0 = t, 1..3 = rgb, 4 = sigma
-  for (int i = lane; i < P; i += 64) {
-    float v[5];
-    if (i < a.Nc) {
-      const size_t g = (size_t)ray * a.Nc + i;
-      v[0] = a.t_c[g]; v[1] = a.rgb_c[g * 3]; v[2] = a.rgb_c[g * 3 + 1]; v[3] = a.rgb_c[g * 3 + 2]; v[4] = a.sig_c[g];
-    } else if (i < N) {
-      const size_t g = (size_t)ray * a.Nf + (i - a.Nc);
-      v[0] = a.t_f[g]; v[1] = a.rgb_f[g * 3]; v[2] = a.rgb_f[g * 3 + 1]; v[3] = a.rgb_f[g * 3 + 2]; v[4] = a.sig_f[g];
-    } else {
-      v[0] = v[1] = v[2] = v[3] = v[4] = __builtin_nanf("");  // padding = the maximum key: behind every real value, NaNs included
-    }
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      val[c * P + i] = v[c];
-      if (WITH_IDX) idx[c * P + i] = (uint16_t)i;
-    }
-  }
-  __syncthreads();
-  const size_t gN = (size_t)ray * N;
-  merge_ray_sort_composite<WITH_IDX>(val, idx, P, N, a.last, lane, a.w ? a.w + gN : nullptr, a.bundle ? a.bundle + gN * 5 : nullptr,
-                                     (WITH_IDX && a.perm) ? a.perm + (size_t)ray * 5 * N : nullptr, a.C_fine + (size_t)ray * 3,
-                                     [] { __syncthreads(); });
+  float* val = reinterpret_cast<float*>(smem_raw);                      // [5][P]
+  uint16_t* idx = reinterpret_cast<uint16_t*>(val + 5 * (size_t)a.P);  // [5][P]
+  merge_ray_stage<WITH_IDX>(a, blockIdx.x, threadIdx.x, val, idx, [] { __syncthreads(); });
 }
 
 // ---------------------------------------------------------------------------------------------

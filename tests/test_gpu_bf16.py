@@ -378,7 +378,7 @@ def _variant(tmp_path, name, env_extra, B=96):
 
     from conftest import ROOT
 
-    env = {k: v for k, v in os.environ.items() if k not in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16", "NERF_BF16_4WAVE", "NERF_DW_BF16_SMALLGROUP")}
+    env = {k: v for k, v in os.environ.items() if k not in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16", "NERF_BF16_4WAVE", "NERF_DW_BF16_SMALLGROUP", "NERF_FUSE_RAYS")}
     env.update(env_extra)
     out = str(tmp_path / (name + ".pt"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "bf16_variant_dump.py"), out, str(B)], capture_output=True, text=True,
@@ -451,4 +451,21 @@ def test_four_wave_training_workgroups_equal_eight_wave_ones(tmp_path):
             assert torch.equal(four[k], eight[k]), (B, k)
         assert four["loss"] == eight["loss"]
         for i, (a, b) in enumerate(zip(four["grads"], eight["grads"])):
+            assert torch.equal(a, b), (B, i)
+
+
+@pytest.mark.timeout(900)
+def test_ray_stages_fused_into_the_field_launches_equal_separate_launches(tmp_path):
+    """Small bf16 training batches (Nc = 64, Nf = 128): k_coarse / k_merge run as EPILOGUES of the coarse / fine forward launch and
+    k_merge_bwd / k_coarse_bwd as PROLOGUES of the fine / coarse chain launch, on the workgroup's own rays (kernels.h FwdFuse / BwdFuse)
+    instead of four launches of their own (NERF_FUSE_RAYS=0, a process of its own).  The same functions (ray_parts.h, ray_parts_bwd.h) on the
+    same buffers: colours, loss, the resampled depths and every gradient bit for bit; an odd batch (a workgroup with a ray behind the
+    batch) and one with several workgroup rounds."""
+    for B in (97, 256, 400):
+        fused = _variant(tmp_path, f"fuse1_{B}", {"NERF_FUSE_RAYS": "1", "NERF_DW_BF16_MULTI": "1"}, B)
+        sep = _variant(tmp_path, f"fuse0_{B}", {"NERF_FUSE_RAYS": "0", "NERF_DW_BF16_MULTI": "1"}, B)
+        for k in ("Cc", "Cf", "train_t_f", "train_w_c", "train_bundle", "train_perm"):
+            assert torch.equal(fused[k], sep[k]), (B, k)
+        assert fused["loss"] == sep["loss"]
+        for i, (a, b) in enumerate(zip(fused["grads"], sep["grads"])):
             assert torch.equal(a, b), (B, i)

@@ -46,6 +46,9 @@ def main():
     res["train_packed_bf"] = region("packed_bf", img_bytes)
     res["rayf"] = region("rayf", B * 24 * 4)
     res["t_c"] = region("t_c", B * Nc * 4)
+    torch.cuda.synchronize()
+    for name, n in (("t_f", B * Nf * 4), ("w_c", B * Nc * 4), ("bundle", B * (Nc + Nf) * 5 * 4), ("perm", B * 5 * (Nc + Nf) * 2)):
+        res["train_" + name] = region(name, n)  # what the forward's per-ray stages left in the training workspace
     loss = m.ray_loss(Cc, Cf, Ct.to(dev))
     loss.backward()
     torch.cuda.synchronize()
@@ -79,7 +82,7 @@ def main():
     st = C.c_uint32(0)
     _abi.check(_abi.lib().nerf_hip_read_status_sticky(ws.data_ptr(), ws.numel(), C.byref(st), 0, torch.cuda.current_stream(dev).cuda_stream))
     res["sticky"] = int(st.value)
-    res["env"] = {k: os.environ.get(k) for k in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16", "NERF_BF16_4WAVE")}
+    res["env"] = {k: os.environ.get(k) for k in ("NERF_PREP_BF16", "NERF_DW_BF16_MULTI", "NERF_PAIR_BF16", "NERF_BF16_4WAVE", "NERF_FUSE_RAYS")}
     torch.save(res, out)
     print("DUMP-OK", res["env"], flush=True)
 
