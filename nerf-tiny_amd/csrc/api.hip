@@ -189,7 +189,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
     L.drgb_f = take(b * Nf * 12);
     L.dsig_f = take(b * Nf * 4);
     L.dt_f = take(b * Nf * 4);
-    L.dC = take(b * 6 * 4);  // d loss / d C_coarse, d loss / d C_fine of nerf_hip_train_step
+    L.dC = take(b * 9 * 4);  // nerf_hip_train_step: d loss / d C_coarse, d loss / d C_fine, the loss's summands ([B][3] each)
   }
   L.total = o;
   return L;
@@ -295,9 +295,40 @@ int nerf_hip_ws_bytes(int B, int Nc, int Nf, int flags, size_t* bytes) {
   return NERF_HIP_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// what nerf_hip_train_step hands to the forward / backward it is made of: with the per-ray stages fused into the field launches (small
+// bf16 batches) ray_loss rides along (kernels.h FwdFuse / BwdFuse) and `fused` comes back true -- the caller then launches no k_ray_loss
+struct TrainLoss {
+  const float* C_true;
+  float *dC_c, *dC_f, *terms, *loss;
+  bool fused;
+};
+int forward_impl(const float* const* weights24, const int64_t* row, const int64_t* col, const float* poses_bound, const float* K_inv9,
+                 const float* ray0_near_far, int B, int Nc, int Nf, float last_delta, float* C_coarse, float* C_fine, void* ws, size_t ws_bytes,
+                 int flags, void* stream, TrainLoss* tl);
+int backward_impl(const float* const* weights24, const float* dC_coarse, const float* dC_fine, const float* ray0_near_far, int B, int Nc, int Nf,
+                  float last_delta, float* const* dweights24, void* ws, size_t ws_bytes, int flags, void* stream, void* early_event,
+                  const TrainLoss* tl);
+}  // namespace
+
+extern "C" {
+
 int nerf_hip_forward(const float* const* weights24, const int64_t* row, const int64_t* col, const float* poses_bound,
                      const float* K_inv9, const float* ray0_near_far, int B, int Nc, int Nf, float last_delta, float* C_coarse,
                      float* C_fine, void* ws, size_t ws_bytes, int flags, void* stream) {
+  return forward_impl(weights24, row, col, poses_bound, K_inv9, ray0_near_far, B, Nc, Nf, last_delta, C_coarse, C_fine, ws, ws_bytes, flags, stream,
+                      nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+int forward_impl(const float* const* weights24, const int64_t* row, const int64_t* col, const float* poses_bound, const float* K_inv9,
+                 const float* ray0_near_far, int B, int Nc, int Nf, float last_delta, float* C_coarse, float* C_fine, void* ws, size_t ws_bytes,
+                 int flags, void* stream, TrainLoss* tl) {
   if (int rc = check_sizes(B, Nc, Nf)) return rc;
   if (int rc = check_weights(weights24)) return rc;
   if (!row || !col || !poses_bound || !K_inv9 || !C_coarse || !C_fine || !ws) return fail(NERF_HIP_ERR_ARG, "null argument");
@@ -447,6 +478,10 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   ma.C_fine = C_fine;
   if (fuse_rays) {
     ff.mode = 2; ff.m = ma;
+    if (tl) {  // inside nerf_hip_train_step: ray_loss's per-element work rides in the same epilogue
+      ff.C_true = tl->C_true; ff.C_coarse = C_coarse; ff.dC_c = tl->dC_c; ff.dC_f = tl->dC_f; ff.loss_terms = tl->terms;
+      tl->fused = true;
+    }
     { ProfScope ps(NERF_HIP_K_FIELD_FINE, st, &pc); HIP_TRY(field(fa)); }
   } else {
     { ProfScope ps(NERF_HIP_K_FIELD_FINE, st, &pc); HIP_TRY(field(fa)); }
@@ -454,6 +489,10 @@ int nerf_hip_forward(const float* const* weights24, const int64_t* row, const in
   }
   return NERF_HIP_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int nerf_hip_profile_begin(int max_launches) {
   if (g_prof.ev) return fail(NERF_HIP_ERR_ARG, "profile already active");
@@ -504,6 +543,17 @@ int nerf_hip_backward(const float* const* weights24, const float* dC_coarse, con
 int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coarse, const float* dC_fine, const float* ray0_near_far,
                               int B, int Nc, int Nf, float last_delta, float* const* dweights24, void* ws, size_t ws_bytes, int flags,
                               void* stream, void* early_event) {
+  return backward_impl(weights24, dC_coarse, dC_fine, ray0_near_far, B, Nc, Nf, last_delta, dweights24, ws, ws_bytes, flags, stream, early_event,
+                       nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+int backward_impl(const float* const* weights24, const float* dC_coarse, const float* dC_fine, const float* ray0_near_far, int B, int Nc, int Nf,
+                  float last_delta, float* const* dweights24, void* ws, size_t ws_bytes, int flags, void* stream, void* early_event,
+                  const TrainLoss* tl) {
   if (int rc = check_sizes(B, Nc, Nf)) return rc;
   if (int rc = check_weights(weights24)) return rc;
   if (int rc = check_weights(const_cast<const float* const*>(dweights24))) return rc;
@@ -561,7 +611,10 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
   fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf; fb.wb0 = wb_c;
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
   auto chain = [&](const FieldBwdArgs& f, bool fine) { return bf16 ? launch_field_bwd_bf16(f, fine, st, bz.mode ? &bz : nullptr) : tile_kernel ? launch_field_bwd(f, fine, st) : launch_field_bwd_reg(f, fine, st); };
-  if (fuse_rays) { bz.mode = 1; bz.m = mb; }
+  if (fuse_rays) {
+    bz.mode = 1; bz.m = mb;
+    if (tl && tl->fused) { bz.loss_terms = tl->terms; bz.loss = tl->loss; }  // block 0 of the fine chain adds up the loss's summands
+  }
   { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st, &pc); HIP_TRY(chain(fb, true)); }
   bz.mode = 0;
 
@@ -782,6 +835,10 @@ int nerf_hip_backward_overlap(const float* const* weights24, const float* dC_coa
   return NERF_HIP_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int nerf_hip_train_step(const float* const* weights24, const int64_t* row, const int64_t* col, const float* poses_bound,
                         const float* K_inv9, const float* ray0_near_far, const float* C_true, int B, int Nc, int Nf, float last_delta,
                         float* C_coarse, float* C_fine, float* loss, float* const* dweights24, void* ws, size_t ws_bytes, int flags,
@@ -789,15 +846,20 @@ int nerf_hip_train_step(const float* const* weights24, const int64_t* row, const
   if (!C_true || !loss || !C_coarse || !C_fine) return fail(NERF_HIP_ERR_ARG, "null argument");
   flags |= NERF_HIP_SAVE_FOR_BACKWARD;
   if (int rc = check_weights(const_cast<const float* const*>(dweights24))) return rc;  // (before anything is enqueued)
-  if (int rc = nerf_hip_forward(weights24, row, col, poses_bound, K_inv9, ray0_near_far, B, Nc, Nf, last_delta, C_coarse, C_fine, ws, ws_bytes,
-                                flags, stream))
-    return rc;
+  if (int rc = check_sizes(B, Nc, Nf)) return rc;
+  if (!ws) return fail(NERF_HIP_ERR_ARG, "null argument");
   const WsLayout L = layout(B, Nc, Nf, flags);
-  float* dCc = at<float>(ws, L.dC);
-  float* dCf = dCc + (size_t)B * 3;
-  if (int rc = nerf_hip_ray_loss(C_coarse, C_fine, C_true, B, loss, dCc, dCf, stream)) return rc;
-  return nerf_hip_backward_overlap(weights24, dCc, dCf, ray0_near_far, B, Nc, Nf, last_delta, dweights24, ws, ws_bytes,
-                                   flags & ~NERF_HIP_WEIGHTS_UNCHANGED, stream, early_event);
+  if (ws_bytes < L.total) return fail(NERF_HIP_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
+  TrainLoss tl;
+  tl.C_true = C_true; tl.dC_c = at<float>(ws, L.dC); tl.dC_f = tl.dC_c + (size_t)B * 3; tl.terms = tl.dC_f + (size_t)B * 3; tl.loss = loss;
+  tl.fused = false;
+  if (int rc = forward_impl(weights24, row, col, poses_bound, K_inv9, ray0_near_far, B, Nc, Nf, last_delta, C_coarse, C_fine, ws, ws_bytes, flags,
+                            stream, &tl))
+    return rc;
+  if (!tl.fused)  // (fused: d loss / d C and the loss's summands came out of the fine pass's epilogue; its sum is taken in the backward)
+    if (int rc = nerf_hip_ray_loss(C_coarse, C_fine, C_true, B, loss, tl.dC_c, tl.dC_f, stream)) return rc;
+  return backward_impl(weights24, tl.dC_c, tl.dC_f, ray0_near_far, B, Nc, Nf, last_delta, dweights24, ws, ws_bytes,
+                       flags & ~NERF_HIP_WEIGHTS_UNCHANGED, stream, early_event, &tl);
 }
 
 int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_t* offset) {

@@ -13,6 +13,7 @@
 #include "bf16_stream.h"
 #include "bf16_weights.h"
 #include "ray_parts_bwd.h"
+#include "ray_parts.h"
 
 #include <string.h>
 
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_bwd_bf16(const FieldBwd
         const int ray = blockIdx.x * (WAVES / 4) + c.wv;
         if (ray < fz.m.B) merge_bwd_ray(fz.m, ray, lane, scr + c.wv * 4 * 192, wave_fence);
       }
+      // the loss VALUE (nobody on the device waits for it): the 3 B summands the forward's epilogues left, added in k_ray_loss's order
+      if (blockIdx.x == 0 && fz.loss_terms) ray_loss_sum<64 * WAVES>(fz.loss_terms, 3 * fz.m.B, fz.loss, scr + 4 * 4 * 192, threadIdx.x);
     } else {
       if (c.wv < WAVES / 2) {
         const int ray_raw = blockIdx.x * (WAVES / 2) + c.wv;

@@ -252,12 +252,37 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16(const FieldArg
           float* w = scr + c.wv * 3 * 64;
           coarse_ray_stage(fz.c, blockIdx.x * (WAVES / 2) + c.wv, lane_f, w, w + 64, w + 128, wave_fence);
         }
-      } else {                   // k_merge<true>: WAVES / 4 rays
-        if (c.wv < WAVES / 4) {
-          const int ray = blockIdx.x * (WAVES / 4) + c.wv;
+      } else {                   // k_merge<true>: WAVES / 4 rays.  Their 5 (WAVES / 4) channel sorts -- five independent sorts per ray (quirk
+        // Q1) -- are dealt out over ALL waves, one 256-slot channel per job (the one-channel instance of k_merge's register network with
+        // the original slots: the same compare-exchanges, the same permutation); then one wave per ray composites.
+        constexpr int R = WAVES / 4;
+        float* const val0 = scr;                                                   // [R][5][256] floats
+        uint16_t* const idx0 = reinterpret_cast<uint16_t*>(scr + R * 5 * 256);    // [R][5][256] u16
+        for (int j = c.wv; j < 5 * R; j += WAVES) {
+          const int rl = j / 5, ch = j - 5 * rl;
+          const int ray = blockIdx.x * R + rl;
+          if (ray < fz.m.B) merge_channel_job(fz.m, ray, ch, lane_f, val0 + (rl * 5 + ch) * 256, idx0 + (rl * 5 + ch) * 256);
+        }
+        __syncthreads();
+        if (c.wv < R) {
+          const int ray = blockIdx.x * R + c.wv;
           if (ray < fz.m.B) {
-            float* val = scr + c.wv * (5 * 256 + 5 * 128);  // [5][256] floats + [5][256] u16
-            merge_ray_stage<true>(fz.m, ray, lane_f, val, reinterpret_cast<uint16_t*>(val + 5 * 256), wave_fence);
+            constexpr int N = 192;
+            const size_t gN = (size_t)ray * N;
+            merge_ray_composite<true>(val0 + c.wv * 5 * 256, idx0 + c.wv * 5 * 256, 256, N, fz.m.last, lane_f, fz.m.w ? fz.m.w + gN : nullptr,
+                                      fz.m.bundle ? fz.m.bundle + gN * 5 : nullptr, fz.m.perm ? fz.m.perm + (size_t)ray * 5 * N : nullptr,
+                                      fz.m.C_fine + (size_t)ray * 3);
+            if (fz.C_true) {  // ray_loss's per-element work (inside nerf_hip_train_step): this ray's three elements
+              wave_fence();    // C_fine of this ray (lane 0's stores) is readable
+              if (lane_f < 3) {
+                const size_t e = (size_t)ray * 3 + lane_f;
+                float d1, d2, term;
+                ray_loss_element(fz.C_coarse[e], fz.m.C_fine[e], fz.C_true[e], d1, d2, term);
+                fz.dC_c[e] = d1;
+                fz.dC_f[e] = d2;
+                fz.loss_terms[e] = term;
+              }
+            }
           }
         }
       }

@@ -112,6 +112,13 @@ struct FwdFuse {
   int mode;      // 1: coarse composite + resampling behind the coarse pass, 2: merge + sorts + composite behind the fine pass
   CoarseArgs c;
   MergeArgs m;
+  // mode 2 inside nerf_hip_train_step: ray_loss's per-element work rides along too (nerf.py:325-331) -- d loss / d C and the summands of the
+  // loss, element by element as k_ray_loss forms them; the SUM is taken by the first block of the fine chain launch (BwdFuse), in
+  // k_ray_loss's order.  C_true null: no loss here
+  const float* C_true;    // [B][3]
+  const float* C_coarse;  // [B][3] (written by the coarse pass's epilogue, an earlier launch)
+  float *dC_c, *dC_f;     // [B][3]
+  float* loss_terms;      // [B][3]
 };
 hipError_t launch_pack_weights(const Weights24& w, float* fold, float4* out, int nseg, hipStream_t st);  // fold: FOLD_FLOATS scratch (launch_fold_weights runs first)
 hipError_t launch_fold_weights(const Weights24& w, float* fold, hipStream_t st);  // fold: FOLD_FLOATS (b_fold, then W_fold): bf16-MLP variant
@@ -268,6 +275,8 @@ struct BwdFuse {
   int mode;      // 1: merged-composite backward in front of the fine chain, 2: resampling + coarse-composite backward in front of the coarse chain
   MergeBwdArgs m;
   CoarseBwdArgs c;
+  const float* loss_terms;  // mode 1, or null: block 0 adds up the 3 B summands of the loss in k_ray_loss's order
+  float* loss;              // [1]
 };
 
 struct SmallGradArgs {

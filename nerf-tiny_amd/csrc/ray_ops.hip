@@ -61,10 +61,11 @@ __global__ __launch_bounds__(1024) void k_ray_loss(const float* Cc, const float*
   __shared__ float red[16];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    const float e1 = Cc[i] - Ct[i], e2 = Cf[i] - Ct[i];
-    acc += e1 * e1 + e2 * e2;
-    if (dCc) dCc[i] = 2.0f * e1;
-    if (dCf) dCf[i] = 2.0f * e2;
+    float d1, d2, term;
+    ray_loss_element(Cc[i], Cf[i], Ct[i], d1, d2, term);
+    acc += term;
+    if (dCc) dCc[i] = d1;
+    if (dCf) dCf[i] = d2;
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;

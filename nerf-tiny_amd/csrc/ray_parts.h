@@ -234,6 +234,42 @@ __device__ __forceinline__ void sort256_one_channel(float (&v)[4], int lane) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = sort_unkey(key[0][r]);
 }
+// ... and WITH the original slots (the training form: a stable sort whose permutation the backward un-sorts through): on return ix[r] =
+// the slot the value at sorted position 4 lane + r came from
+__device__ __forceinline__ void sort256_one_channel_idx(float (&v)[4], unsigned (&ixo)[4], int lane) {
+  unsigned key[1][4], ix[1][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { key[0][r] = sort_key(v[r]); ix[0][r] = (unsigned)(4 * lane + r); }
+  sortreg_from<true, 2, 1>(key, ix, lane);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { v[r] = sort_unkey(key[0][r]); ixo[r] = ix[0][r]; }
+}
+// channel `ch` (0 = t, 1..3 = rgb, 4 = sigma) of slot i of a ray's merged bundle as k_merge loads it: coarse samples first, then fine, NaN padding
+__device__ __forceinline__ float merge_slot_value(const MergeArgs& a, const int ray, const int ch, const int i) {
+  const int N = a.Nc + a.Nf;
+  if (i < a.Nc) {
+    const size_t g = (size_t)ray * a.Nc + i;
+    return ch == 0 ? a.t_c[g] : ch == 4 ? a.sig_c[g] : a.rgb_c[g * 3 + (ch - 1)];
+  }
+  if (i < N) {
+    const size_t g = (size_t)ray * a.Nf + (i - a.Nc);
+    return ch == 0 ? a.t_f[g] : ch == 4 ? a.sig_f[g] : a.rgb_f[g * 3 + (ch - 1)];
+  }
+  return __builtin_nanf("");
+}
+// ONE (ray, channel) sort job of k_merge<true> at P = 256 by one wave: load, sort with slots, leave the sorted channel in val [256] / idx [256]
+__device__ __forceinline__ void merge_channel_job(const MergeArgs& a, const int ray, const int ch, const int lane, float* val, uint16_t* idx) {
+  float v[4];
+  unsigned ix[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = merge_slot_value(a, ray, ch, 4 * lane + r);
+  sort256_one_channel_idx(v, ix, lane);
+  *reinterpret_cast<float4*>(val + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
+  uint2 pk;
+  pk.x = ix[0] | (ix[1] << 16);
+  pk.y = ix[2] | (ix[3] << 16);
+  *reinterpret_cast<uint2*>(idx + 4 * lane) = pk;
+}
 
 template <bool WITH_IDX>
 __device__ __forceinline__ void merge_ray_composite(const float* val, const uint16_t* idx, int P, int N, float last, int lane, float* w_out,
@@ -380,6 +416,36 @@ __device__ __forceinline__ void merge_ray_stage(const MergeArgs& a, const int ra
   const size_t gN = (size_t)ray * N;
   merge_ray_sort_composite<WITH_IDX>(val, idx, P, N, a.last, lane, a.w ? a.w + gN : nullptr, a.bundle ? a.bundle + gN * 5 : nullptr,
                                      (WITH_IDX && a.perm) ? a.perm + (size_t)ray * 5 * N : nullptr, a.C_fine + (size_t)ray * 3, sync);
+}
+
+// ---- ray_loss (nerf.py:325-331) in two pieces, bit-compatible with k_ray_loss (ray_ops.hip) ----
+// element (ray, ch): e1 = C_c - C*, e2 = C_f - C*; d loss / d C_c = 2 e1, d loss / d C_f = 2 e2; summand = e1 e1 + e2 e2
+__device__ __forceinline__ void ray_loss_element(float cc, float cf, float ct, float& dcc, float& dcf, float& term) {
+  const float e1 = cc - ct, e2 = cf - ct;
+  dcc = 2.0f * e1;
+  dcf = 2.0f * e2;
+  term = e1 * e1 + e2 * e2;
+}
+// the sum of n summands in k_ray_loss's order -- 1,024 virtual threads each adding its strided elements, a butterfly over each of the 16
+// virtual waves, the 16 wave sums added in order -- by a workgroup of T = 256 or 512 threads (every thread plays 1024 / T virtual ones);
+// red: 16 floats of LDS; every thread of the workgroup calls it, thread 0 stores the result
+template <int T>
+__device__ __forceinline__ void ray_loss_sum(const float* terms, int n, float* loss, float* red, int tid) {
+  static_assert(1024 % T == 0 && T % 64 == 0, "whole virtual waves per real wave");
+#pragma unroll
+  for (int v = 0; v < 1024 / T; ++v) {
+    const int vt = tid + v * T;  // virtual thread id
+    float acc = 0.f;
+    for (int i = vt; i < n; i += 1024) acc += terms[i];
+    acc = wave_sum(acc);
+    if ((vt & 63) == 0) red[vt >> 6] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    loss[0] = s;
+  }
 }
 
 }  // namespace nerf
