@@ -228,29 +228,56 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16(const FieldArg
     a.sigma[m_e] = fabsf(spre);
     if (SAVE) a.spre[a.row0 + m_e] = spre;
   }
+  // fused per-ray stage behind this pass (kernels.h FwdFuse): it takes the workgroup's sigma / rgb from LDS -- this wave's slot of the parked
+  // direction encodings, read back just above -- so that it does not have to wait for the stores (and, with them, for every save of the
+  // stream in front of them in the queue) to reach memory
+  unsigned char* const park_w = lds + BF_LDS_BYTES + c.wv * 2048;
+  if (SAVE && fz.mode != 0 && lane_e < 32) reinterpret_cast<float*>(park_w)[lane_e] = fabsf(spre);
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
   bf_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, X, nullptr, nothing_f, last_of(relu_to(X, BS_C, 8, 4), 3));
-  if (out_e) {
-    a.rgb[(size_t)m_e * 3 + 0] = 1.0f / (1.0f + expf(-acc[1][0]));
-    a.rgb[(size_t)m_e * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
-    a.rgb[(size_t)m_e * 3 + 2] = 1.0f / (1.0f + expf(-acc[1][2]));
+  {
+    const float r0 = 1.0f / (1.0f + expf(-acc[1][0])), r1 = 1.0f / (1.0f + expf(-acc[1][1])), r2 = 1.0f / (1.0f + expf(-acc[1][2]));
+    if (out_e) {
+      a.rgb[(size_t)m_e * 3 + 0] = r0;
+      a.rgb[(size_t)m_e * 3 + 1] = r1;
+      a.rgb[(size_t)m_e * 3 + 2] = r2;
+    }
+    if (SAVE && fz.mode != 0 && lane_e < 32) {
+      float* pr = reinterpret_cast<float*>(park_w + 128) + 3 * lane_e;
+      pr[0] = r0; pr[1] = r1; pr[2] = r2;
+    }
   }
   // ---- SMALL batches (kernels.h FwdFuse): the per-ray stage that would be the next launch runs HERE, on the workgroup's own rays -- its
   // samples are whole rays (32 WAVES = 2 or 4 coarse rays of 64, 1 or 2 fine rays of 128).  Behind a barrier: every wave's sigma / rgb
   // stores have completed (same CU: write-through L1, lines nobody has read in this launch) and the ring is free to be scratch.
   if constexpr (SAVE) {
     if (fz.mode != 0) {  // (kernel argument: uniform)
-      __syncthreads();
+      // LDS only: the slots are written, nobody reads the ring any more -- NOT a wait for the stores of the stream (no vmcnt here)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       float* const scr = reinterpret_cast<float*>(lds + BF_BIAS_BYTES);
+      const unsigned char* const park = lds + BF_LDS_BYTES;
       const int lane_f = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-      auto wave_fence = [] {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      auto wave_fence = [] {  // this wave's LDS writes before its LDS reads
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
       };
       if (fz.mode == 1) {        // k_coarse: one ray per wave, WAVES / 2 rays
         if (c.wv < WAVES / 2) {
-          float* w = scr + c.wv * 3 * 64;
-          coarse_ray_stage(fz.c, blockIdx.x * (WAVES / 2) + c.wv, lane_f, w, w + 64, w + 128, wave_fence);
+          float* w = scr + c.wv * (3 * 64 + 4 * 64);
+          float* sg = w + 3 * 64;   // the ray's sigma [64] and rgb [64][3], gathered from the two waves' slots that hold them
+          float* cl = sg + 64;
+          sg[lane_f] = park_sigma(park, 64 * c.wv + lane_f);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) cl[3 * lane_f + k] = park_rgb(park, 64 * c.wv + lane_f, k);
+          wave_fence();
+          const int ray_raw = blockIdx.x * (WAVES / 2) + c.wv;
+          const size_t g0 = (size_t)(ray_raw < fz.c.B ? ray_raw : fz.c.B - 1) * 64;
+          CoarseArgs ca = fz.c;
+          ca.sigma = sg - g0;  // (the stage indexes [ray * Nc + i]: i = 0 lands on the scratch)
+          ca.rgb = cl - 3 * g0;
+          coarse_ray_stage(ca, ray_raw, lane_f, w, w + 64, w + 128, wave_fence);
         }
       } else {                   // k_merge<true>: WAVES / 4 rays.  Their 5 (WAVES / 4) channel sorts -- five independent sorts per ray (quirk
         // Q1) -- are dealt out over ALL waves, one 256-slot channel per job (the one-channel instance of k_merge's register network with
@@ -261,23 +288,26 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16(const FieldArg
         for (int j = c.wv; j < 5 * R; j += WAVES) {
           const int rl = j / 5, ch = j - 5 * rl;
           const int ray = blockIdx.x * R + rl;
-          if (ray < fz.m.B) merge_channel_job(fz.m, ray, ch, lane_f, val0 + (rl * 5 + ch) * 256, idx0 + (rl * 5 + ch) * 256);
+          if (ray < fz.m.B) merge_channel_job(fz.m, ray, ch, lane_f, val0 + (rl * 5 + ch) * 256, idx0 + (rl * 5 + ch) * 256, park, 128 * rl);
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         if (c.wv < R) {
           const int ray = blockIdx.x * R + c.wv;
           if (ray < fz.m.B) {
             constexpr int N = 192;
             const size_t gN = (size_t)ray * N;
+            float cfin[3];
             merge_ray_composite<true>(val0 + c.wv * 5 * 256, idx0 + c.wv * 5 * 256, 256, N, fz.m.last, lane_f, fz.m.w ? fz.m.w + gN : nullptr,
                                       fz.m.bundle ? fz.m.bundle + gN * 5 : nullptr, fz.m.perm ? fz.m.perm + (size_t)ray * 5 * N : nullptr,
-                                      fz.m.C_fine + (size_t)ray * 3);
+                                      fz.m.C_fine + (size_t)ray * 3, cfin);
             if (fz.C_true) {  // ray_loss's per-element work (inside nerf_hip_train_step): this ray's three elements
-              wave_fence();    // C_fine of this ray (lane 0's stores) is readable
               if (lane_f < 3) {
                 const size_t e = (size_t)ray * 3 + lane_f;
+                const float cf = lane_f == 0 ? cfin[0] : (lane_f == 1 ? cfin[1] : cfin[2]);  // (C_fine from the registers, not read back)
                 float d1, d2, term;
-                ray_loss_element(fz.C_coarse[e], fz.m.C_fine[e], fz.C_true[e], d1, d2, term);
+                ray_loss_element(fz.C_coarse[e], cf, fz.C_true[e], d1, d2, term);
                 fz.dC_c[e] = d1;
                 fz.dC_f[e] = d2;
                 fz.loss_terms[e] = term;

@@ -257,12 +257,24 @@ __device__ __forceinline__ float merge_slot_value(const MergeArgs& a, const int 
   }
   return __builtin_nanf("");
 }
+// sigma / rgb of the workgroup's OWN fine samples as the bf16 training forward leaves them in LDS for its epilogue: wave w's 32 samples in a
+// 2-KiB slot of their own (sigma [32] at +0, rgb [32][3] at +128 bytes); s = sample index inside the workgroup
+__device__ __forceinline__ float park_sigma(const unsigned char* park, int s) { return reinterpret_cast<const float*>(park + 2048 * (s >> 5))[s & 31]; }
+__device__ __forceinline__ float park_rgb(const unsigned char* park, int s, int c) { return reinterpret_cast<const float*>(park + 2048 * (s >> 5) + 128)[3 * (s & 31) + c]; }
+
 // ONE (ray, channel) sort job of k_merge<true> at P = 256 by one wave: load, sort with slots, leave the sorted channel in val [256] / idx [256]
-__device__ __forceinline__ void merge_channel_job(const MergeArgs& a, const int ray, const int ch, const int lane, float* val, uint16_t* idx) {
+// park != null: the fine samples' sigma / rgb come from the workgroup's LDS slots (s0 = the ray's first sample inside the workgroup) instead of
+// a.sig_f / a.rgb_f -- the same values, without waiting for their stores
+__device__ __forceinline__ void merge_channel_job(const MergeArgs& a, const int ray, const int ch, const int lane, float* val, uint16_t* idx,
+                                                  const unsigned char* park = nullptr, const int s0 = 0) {
   float v[4];
   unsigned ix[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = merge_slot_value(a, ray, ch, 4 * lane + r);
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * lane + r;
+    if (park && ch != 0 && i >= a.Nc && i < a.Nc + a.Nf) v[r] = ch == 4 ? park_sigma(park, s0 + i - a.Nc) : park_rgb(park, s0 + i - a.Nc, ch - 1);
+    else v[r] = merge_slot_value(a, ray, ch, i);
+  }
   sort256_one_channel_idx(v, ix, lane);
   *reinterpret_cast<float4*>(val + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
   uint2 pk;
@@ -273,7 +285,7 @@ __device__ __forceinline__ void merge_channel_job(const MergeArgs& a, const int 
 
 template <bool WITH_IDX>
 __device__ __forceinline__ void merge_ray_composite(const float* val, const uint16_t* idx, int P, int N, float last, int lane, float* w_out,
-                                                    float* bundle_out, uint16_t* perm_out, float* C_out);
+                                                    float* bundle_out, uint16_t* perm_out, float* C_out, float* c_ret = nullptr);
 
 // nerf.py:302-321 behind the load: val [5][P] (channel 0 = t, 1..3 = rgb, 4 = sigma; slots >= N padded with NaN) and, WITH_IDX, idx [5][P]
 // = the original slot, in LDS -> five independent ascending channel sorts (quirk Q1), delta_i = t_{i+1} - t_i with the last = `last`,
@@ -319,7 +331,7 @@ __device__ __forceinline__ void merge_ray_sort_composite(float* val, uint16_t* i
 // the composite over the SORTED channels val [5][P] (and idx): delta_i = t_{i+1} - t_i with the last = `last`, weights, C_fine[3]
 template <bool WITH_IDX>
 __device__ __forceinline__ void merge_ray_composite(const float* val, const uint16_t* idx, int P, int N, float last, int lane, float* w_out,
-                                                    float* bundle_out, uint16_t* perm_out, float* C_out) {
+                                                    float* bundle_out, uint16_t* perm_out, float* C_out, float* c_ret) {
   double carry = 0.0;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   for (int base = 0; base < N; base += 64) {
@@ -354,6 +366,11 @@ __device__ __forceinline__ void merge_ray_composite(const float* val, const uint
     C_out[0] = c0;
     C_out[1] = c1;
     C_out[2] = c2;
+  }
+  if (c_ret) {  // (the sums are wave-uniform: every lane holds them)
+    c_ret[0] = c0;
+    c_ret[1] = c1;
+    c_ret[2] = c2;
   }
 }
 
