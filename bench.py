@@ -355,7 +355,7 @@ def rooflines(leg, prof, b_local, steps):
                        "the products run on the bf16 pipe with 16-bit-mantissa operands (parity: `parity.split_mlp_vs_reference`)"}
         return blk, None
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
-    fwd_key = (["k_field_fwd_bf16<true>"] if leg.train else ["k_field_fwd_bf16x<2, 8>"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
+    fwd_key = (["k_field_fwd_bf16<true, 8>"] if leg.train else ["k_field_fwd_bf16x<2, 8>"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
     if "render_pair" in prof:  # small bf16-MLP inference batches: ONE launch holds both field passes and both composites of every ray pair
         fwd = mfma("k_render_pair_bf16x (the whole forward of a ray pair per workgroup: both field passes, coarse composite + resampling, merge + sorts + "
                    "composite in one launch)", ("render_pair",), FLOP_PER_SAMPLE * b_local * (NC + NF), fwd_key, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)
@@ -372,7 +372,7 @@ def rooflines(leg, prof, b_local, steps):
     chain_exec = 1.0 - 2 * 65536 * (NC + NF) / (CHAIN_FLOP_COARSE * NC + CHAIN_FLOP_FINE * NF)  # the fold removes 65,536 MACs per sample
     chain = mfma(f"k_field_bwd_{sfx} (dX chain; average of the fine- and coarse-pass launches)",
                  ("bwd_field_fine", "bwd_field_coarse"), (CHAIN_FLOP_COARSE * b_local * NC + CHAIN_FLOP_FINE * b_local * NF) // 2,
-                 [f"k_field_bwd_{sfx}<true>", f"k_field_bwd_{sfx}<false>"], chain_exec)
+                 [f"k_field_bwd_{sfx}<true, 8>", f"k_field_bwd_{sfx}<false, 8>"] if leg.bf16 else [f"k_field_bwd_{sfx}<true>", f"k_field_bwd_{sfx}<false>"], chain_exec)
     # weight-gradient phase: all dW = G^T X products of one step (same MACs as one forward over all samples) + slab reduces + thin heads
     dw_ms = prof.get("bwd_dw", (0.0, 0))[0] / max(prof.get("bwd_dw", (0.0, 1))[1], 1)
     launches = DW_BF16_LAUNCHES if leg.bf16 else DW_LAUNCHES
@@ -415,10 +415,9 @@ def rooflines(leg, prof, b_local, steps):
 # colour head, the reduce, the fold's gradient kernel and the three small kernels of dir_info's direction-encoding columns
 DW_LAUNCHES = {"k_dw4_group": 1, "k_dw4<4, true>": 1, "k_dw4<2, false>": 2, "k_dw_thin": 1, "k_dw_reduce": 1, "k_fold_grads": 1,
                "k_dir_prep": 1, "k_dir_gamma_part": 1, "k_dir_gamma_final": 1}
-# bf16-MLP variant (dw_bf16.hip): layer 0, the six 256 x 256 products in one launch, layer 4, the folded product with the sigma head,
-# the colour head, ONE launch for all slab sums, the fold's gradient kernel
-DW_BF16_LAUNCHES = {"k_dw_bf16<2, false>": 1, "k_dw_bf16<8, false>": 1, "k_dw_bf16<10, false>": 1, "k_dw_bf16<9, true>": 1,
-                    "k_dw_bf16<4, false>": 1, "k_dw_bf16_reduce_batch": 1, "k_fold_grads": 1}
+# bf16-MLP variant (dw_bf16.hip), 4096 rays: the six 256 x 256 products in one launch, the products with small blocks (layer 4, layer 0, the
+# folded product with the sigma head, the colour head) in another (k_dw_bf16_multi), ONE launch for all slab sums, the fold's gradient kernel
+DW_BF16_LAUNCHES = {"k_dw_bf16<8, false>": 1, "k_dw_bf16_multi": 1, "k_dw_bf16_reduce_batch": 1, "k_fold_grads": 1}
 DW_BF16_KIB_PER_WAVE_BLOCK = 280  # G and X pieces of bf16_common.h over the products (142 + 138 KiB)
 
 
