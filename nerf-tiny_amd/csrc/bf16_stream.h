@@ -53,9 +53,12 @@ __device__ __forceinline__ unsigned alive_bits(const f32x16& A) {
 
 // The lane id, produced AT this program point (volatile: never merged with an earlier copy, which would have to stay alive -- or be
 // parked in scratch -- across the stream): what the epilogues of the stream kernels form their addresses from.
+// The s_nops in front: the compiler may hand the asm a destination register that overlaps a DEAD row of the accumulator of an MFMA still in
+// flight, and its hazard recognizer does not look inside the asm -- the MFMA's late write then clobbers the lane id (seen in round 4: every
+// lane of an epilogue stored to sample 0).  20 wait states cover the longest MFMA's write-after-write window whatever the allocation.
 __device__ __forceinline__ unsigned lane_id_here() {
   unsigned l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3\n\tv_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
   return l;
 }
 

@@ -1,4 +1,4 @@
-"""CPU checks of the bf16 stream / buffer layout constants in csrc/bf16_common.h and field_fwd_bf16x.hip: the segment starts
+"""CPU checks of the bf16 stream / buffer layout constants in csrc/bf16_common.h and bf16_weights.h: the segment starts
 must be the running sums of (tiles x k-steps) in the order the kernels consume them, the streams must be whole 16-fragment
 chunks (or padded up to one), and the training buffers' per-wave-block sizes must add up.  A silent edit of one constant
 would otherwise only show as wrong numbers on the GPU."""
@@ -45,7 +45,7 @@ def test_backward_stream():
 
 
 def test_forward_stream_16x16x32():
-    c, _ = _consts(os.path.join(CSRC, "field_fwd_bf16x.hip"))
+    c, _ = _consts(os.path.join(CSRC, "bf16_weights.h"))  # (the 16x16x32 image's segment table lives beside its element function)
     segs = [("BXS_L0", 16 * 2), ("BXS_L1", 3 * 16 * 8), ("BXS_L4", 16 * 10), ("BXS_L5", 3 * 16 * 8), ("BXS_SIG", 1 * 8),
             ("BXS_DIR", 8 * 9), ("BXS_COL", 1 * 4)]
     pos = 0
