@@ -17,6 +17,7 @@
 // The kernel is HBM-bound by construction (1 KiB of operands per 128 kFLOP): it is paced by the ring, not by the MFMAs.
 #include "bf16_stream.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -363,10 +364,16 @@ hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base
   // by the ring's per-block latency: profiles/r03_train_bf16_pmc.json -- 256 x 256 products 5.8 TB/s, layer 4 5.4, the folded product 4.3,
   // colour head 3.8, layer 0 3.4); NERF_DW_BF16_COST=0: plain bytes (A/B measurements only)
   static const bool by_cost = [] { const char* e = getenv("NERF_DW_BF16_COST"); return !(e && atoi(e) == 0); }();
+  // NERF_DW_BF16_COSTS="l0,col,fold,l4" (per cent; tuning sweeps only) replaces the shape factors below
+  static const struct Costs { int l0, col, fold, l4; } costs = [] {
+    Costs c{170, 150, 135, 107};
+    if (const char* e = getenv("NERF_DW_BF16_COSTS")) sscanf(e, "%d,%d,%d,%d", &c.l0, &c.col, &c.fold, &c.l4);
+    return c;
+  }();
   int pieces[DwBfMulti::MAXP], total = 0;
   for (int i = 0; i < n; ++i) {
     const int kib = p[i].g_ks + p[i].x1_ks + p[i].x2_ks + (p[i].Z ? 2 : 0), xks = p[i].x1_ks + p[i].x2_ks;
-    const int pct = !by_cost ? 100 : xks == 4 ? 170 : xks == 8 ? 150 : (xks == 18 && p[i].Z) ? 135 : xks == 20 ? 107 : 100;
+    const int pct = !by_cost ? 100 : xks == 4 ? costs.l0 : xks == 8 ? costs.col : (xks == 18 && p[i].Z) ? costs.fold : xks == 20 ? costs.l4 : 100;
     pieces[i] = kib * pct;
     total += pieces[i];
   }
