@@ -18,7 +18,10 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef void __attribute__((address_space(3)))* lptr_t;
 
-constexpr int BF_NS = 8;        // LDS ring slots of the forward kernel (a stream description names its own: S::NS)
+#ifndef NERF_BF_NS  // (timing experiments only: ring depth of the forward stream)
+#define NERF_BF_NS 8
+#endif
+constexpr int BF_NS = NERF_BF_NS;  // LDS ring slots of the forward kernel (a stream description names its own: S::NS)
 constexpr int BF_SYNC_POS = 8;  // fragment position inside a chunk at which the next chunk is published
 constexpr int BF_D = 6;         // fragment reads in flight per wave (<= BF_CHUNK - BF_SYNC_POS); a stream names its own: S::D
 constexpr int BF_EPI_POS = 2;   // k-step of the next tile at which a finished accumulator is consumed

@@ -19,7 +19,10 @@
 
 namespace nerf {
 
-constexpr int BB_NS = 5;
+#ifndef NERF_BB_NS  // (timing experiments only: ring depth of the chain's stream)
+#define NERF_BB_NS 5
+#endif
+constexpr int BB_NS = NERF_BB_NS;
 constexpr int BB_MASK_BYTES = 8 * BM_LAYERS * 1024;  // per workgroup: wave w, layer l at (w * 9 + l) * 1024
 constexpr int BB_LDS_BYTES = BB_MASK_BYTES + BB_NS * BF_CHUNK * BF_FRAG_BYTES;
 

@@ -185,10 +185,12 @@ class NeRFRunner:
         self.last_iter = last_iter
         self.model.bf16_mlp = bool(bf16_mlp)  # an attribute, not part of the checkpoint format: set after a resume too
         self.model.split_mlp = bool(split_mlp)
-        self.bucket = None
+        # the gradients of every step live in ONE flat buffer whose views are p.grad (the kernels write straight into it: no 24 fresh
+        # tensors per iteration) -- the all-reduce buffer of a data-parallel run
+        self.bucket = par.GradBucket(self.model.network.parameters())
         if self.distributed:
             par.broadcast_parameters(self.model.network.parameters(), src=0)  # replicated weights, whatever each rank's RNG drew
-            self.bucket = par.GradBucket(self.model.network.parameters()).enable_overlap()
+            self.bucket.enable_overlap()
 
         def ds(mode):
             if datasets is not None:
@@ -234,19 +236,23 @@ class NeRFRunner:
         rays = {"train": self.train_rays, "val": self.val_rays, "disp": self.disp_rays}[mode]
         it = self.last_iter + 1
         t0, n0 = time.perf_counter(), it
+        self.model.train()
         while it < self.total_iter:
             batches = rays.epoch_sharded(self.batch_ray, self.rank, self.world) if self.distributed else rays.epoch(self.batch_ray)
             for batch in batches:
                 row, col, pix_val, poses_bound, pic = batch[:5]
-                self.optimizer.zero_grad(set_to_none=True)
-                self.model.train()
+                # (no zero_grad: the backward kernels OVERWRITE the bucket's views, which ARE p.grad; FusedAdam.step releases the bucket)
                 if self.distributed:
                     # this rank's slice of the batch: forward + loss + backward into the flat bucket, ONE SUM all-reduce (nerf.py:473-474)
                     _, _, loss = par.train_step_local(self.model, self.bucket, row, col, poses_bound, self.K_inv, pix_val, batch[5],
                                                       self.world, self.group)
                 else:
                     # nerf.py:470-473 (forward, ray_loss, backward) as ONE library call: same kernels, no interpreter between them
-                    _, _, loss = self.model.train_step(row, col, poses_bound, self.K_inv, pix_val)
+                    self.model.grad_bucket = self.bucket
+                    try:
+                        _, _, loss = self.model.train_step(row, col, poses_bound, self.K_inv, pix_val)
+                    finally:
+                        self.model.grad_bucket = None
                 self.optimizer.step()
                 self.scheduler.step()
                 if (it + 1) % self.log_every == 0:  # the only host sync of the loop
