@@ -238,9 +238,10 @@ class Leg:
         self.name, self.train, self.bf16, self.split = name, train, bf16, split  # split: the opt-in split-fp32 inference mode (model.split_mlp)
 
 
-def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
+def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket, time_allreduce=True):
     """W untimed + K timed steps of one configuration, bracketed by barrier + synchronize; returns (elapsed s [max over
-    ranks], per-kernel HIP-event profile of the library, all-reduce ms per step or None)."""
+    ranks], per-kernel HIP-event profile of the library, all-reduce ms per step or None).  time_allreduce=False: no event pair around the
+    collective (two markers per step on the stream are not free at a 0.5 ms step)."""
     import torch
 
     from nerf_tiny_amd import _abi
@@ -263,11 +264,11 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket):
                 loss = model.ray_loss(Cc, Cf, C_true)
                 loss.backward()
             if bucket is not None and dist is not None:  # data-parallel trainer: ONE flat 2.27 MiB SUM all-reduce over RCCL/xGMI
-                if timed:
+                if timed and time_allreduce:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                 bucket.allreduce_sum()
-                if timed:
+                if timed and time_allreduce:
                     e1.record()
                     ar_events.append((e0, e1))
             elif bucket is not None:
@@ -577,6 +578,7 @@ def main():
     ap.add_argument("--autograd-step", action="store_true",
                     help="train legs: forward, ray_loss, backward as three calls through torch.autograd (the reference's call surface) instead of "
                          "NeRFModel.train_step, the one library call NeRFRunner.trainer makes (same kernels, same results)")
+    ap.add_argument("--overlap", action="store_true", help="N > 1 train legs: overlap the early part of the all-reduce with the last weight-gradient products")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the leg named by --mode/--mlp (profiling runs)")
     ap.add_argument("--dry", action="store_true", help="CPU rehearsal of the launcher + process group over gloo (no kernels; tests only)")
@@ -629,8 +631,11 @@ def main():
     model = synth_weights(seed=0).to(dev)
     # the flat gradient buffer of the data-parallel trainer: the backward kernels write into views of it (no pack / unpack)
     bucket = P.parallel.GradBucket(model.network.parameters())
-    if dist is not None:
-        bucket.enable_overlap()  # the all-reduce of point_layer[0..7] (83 % of the bytes) runs beside the last weight-gradient products
+    # --overlap / NERF_DP_OVERLAP=1: the all-reduce of point_layer[0..7] (83 % of the bytes) on a side stream beside the last weight-gradient
+    # products (GradBucket.enable_overlap).  Off by default: on one rank the split launches and the two cross-stream hand-offs cost 46-62 us
+    # per step (scripts/dp_step_proxy.py), as much as an 8-rank ring all-reduce of 2.27 MiB is priced at
+    if dist is not None and (args.overlap or os.environ.get("NERF_DP_OVERLAP") == "1"):
+        bucket.enable_overlap()
 
     def shard(full, lo, hi):
         """Device inputs of rays [lo, hi) of a batch; the model is told its batch size and the GLOBAL ray 0's (near, far): its
@@ -691,57 +696,78 @@ def main():
         proxy = {}
         t_full = {name: (rep["ms_per_step"] if (train, bf16, name.endswith("_split")) == (head.train, head.bf16, head.split) else extra[name]["ms_per_step"])
                   for name, train, bf16, _, _ in legs}
+        # a REAL (single-rank) RCCL group for the collective a rank adds per train step
+        try:
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            dist.init_process_group("nccl", device_id=dev)
+        except Exception as ex:  # no RCCL on this box: the proxy then carries no collective
+            print(f"bench.py: single-rank RCCL group not available: {ex}", file=sys.stderr)
+            dist = None
         for bs in (512, 400):
             s_in = shard(full, 0, bs)
             proxy[str(bs)] = {}
             for name, train, bf16, k, w in legs:
                 leg = Leg(name, train, bf16, name.endswith("_split"))
                 kk = 4 * k
-                e, p, a = run_leg(leg, model, s_in, K, kk, w + 3, dist, dev, bucket)
+                e, p, a = run_leg(leg, model, s_in, K, kk, w + 3, None, dev, bucket)
                 proxy[str(bs)][name] = brief(leg_report(leg, e, p, a, kk, w + 3, 1, bs, True), bs)
+                if train and dist is not None:
+                    # the step a data-parallel rank really makes: the same call + the flat 2.27 MiB SUM all-reduce on the RCCL group behind
+                    # it, timed as ONE loop (the collective's enqueue overlaps the kernels of the step, as it does in NeRFRunner.trainer)
+                    e2, _, _ = run_leg(leg, model, s_in, K, kk, w + 3, dist, dev, bucket, time_allreduce=False)
+                    proxy[str(bs)][name]["dp_step_ms_single_rank"] = round(1e3 * e2 / kk, 4)
         inputs = shard(full, 0, B)
-        # the collective a rank adds per train step, measured on a REAL (single-rank) RCCL group: launch + kernel latency of one flat
-        # 2.27 MiB SUM all-reduce, without the xGMI hops an 8-rank ring adds (those are the driver's 8-GPU run to measure)
+        # ... and the collective ALONE, back to back (host-bound: the enqueue rate of an empty queue, not what a step pays)
         ar1 = None
-        try:
-            if dist is None:
-                sys.stdout.flush()
-                saved_stdout = os.dup(1)
-                os.dup2(2, 1)
-                import torch.distributed as dist
-
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", str(_free_port()))
-                os.environ.setdefault("RANK", "0")
-                os.environ.setdefault("WORLD_SIZE", "1")
-                dist.init_process_group("nccl", device_id=dev)
-            bucket.pending = False
-            for _ in range(5):
-                bucket.allreduce_sum()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(50):
-                bucket.allreduce_sum()
-            e1.record()
-            torch.cuda.synchronize()
-            ar1 = e0.elapsed_time(e1) / 50
-        except Exception as ex:  # no RCCL on this box: the proxy then carries no collective
-            print(f"bench.py: single-rank RCCL all-reduce not measured: {ex}", file=sys.stderr)
+        if dist is not None:
+            try:
+                bucket.pending = False
+                for _ in range(5):
+                    bucket.allreduce_sum()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    bucket.allreduce_sum()
+                e1.record()
+                torch.cuda.synchronize()
+                ar1 = e0.elapsed_time(e1) / 50
+            except Exception as ex:
+                print(f"bench.py: single-rank RCCL all-reduce not measured: {ex}", file=sys.stderr)
         proxy["allreduce_ms_single_rank"] = None if ar1 is None else round(ar1, 4)
-        def implied(ar_ms):
-            return {name: round(t_full[name] / (proxy["512"][name]["ms_per_step"] + (ar_ms if train else 0.0)), 2) for name, train, _, _, _ in legs}
 
-        # UPPER BOUND: the collective of this figure is a single-rank RCCL all-reduce (launch + kernel, no xGMI hop, no straggler)
-        proxy["implied_strong_scaling_8"] = implied(ar1 or 0.0)
+        def implied(ar_ms):
+            """t(4096 rays) / t(a rank's 512-ray step incl. its collective).  ar_ms None: the MEASURED data-parallel step on the single-rank
+            RCCL group (dp_step_ms_single_rank; falls back to t(512) + the stand-alone all-reduce); a number: t(512) + that estimate."""
+            out_ = {}
+            for name, train, _, _, _ in legs:
+                t512 = proxy["512"][name]["ms_per_step"]
+                if train:
+                    t512 = (proxy["512"][name].get("dp_step_ms_single_rank") or t512 + (ar1 or 0.0)) if ar_ms is None else t512 + ar_ms
+                out_[name] = round(t_full[name] / t512, 2)
+            return out_
+
+        # UPPER BOUND: the collective inside this figure ran on a single-rank RCCL group (launch + kernel, no xGMI hop, no straggler)
+        proxy["implied_strong_scaling_8"] = implied(None)
         # ... and with an 8-rank ring's latency in its place.  Not measured (no 8-GPU node was available to any round so far): SURVEY.md 8e
         # prices the un-overlapped 2.27 MiB SUM all-reduce at 30-60 us (latency-bound: 7 xGMI hops x 2 phases; the bytes are 15 us of one
-        # link); the upper end is used, all of it exposed although the overlap (nerf_hip_backward_overlap) hides the early 83 % part's share
+        # link); the upper end is used, all of it exposed
         proxy["ring_allreduce_ms_estimate"] = RING_ALLREDUCE_MS_ESTIMATE
         proxy["implied_strong_scaling_8_with_ring_estimate"] = implied(RING_ALLREDUCE_MS_ESTIMATE)
-        proxy["note"] = ("implied_strong_scaling_8 = t(4096 rays) / (t(512 rays) + single-rank all-reduce for the train legs), all measured in this run on "
-                         "one GPU: an UPPER BOUND (no xGMI hops, no straggler).  implied_strong_scaling_8_with_ring_estimate puts a documented "
-                         f"{RING_ALLREDUCE_MS_ESTIMATE * 1e3:.0f} us estimate of the exposed 8-rank ring all-reduce (SURVEY.md 8e) in its place; the 8-GPU "
+        proxy["note"] = ("implied_strong_scaling_8 = t(4096 rays) / t(512 rays); for the train legs t(512) is dp_step_ms_single_rank = the measured "
+                         "step of a data-parallel rank (NeRFModel.train_step + the flat SUM all-reduce behind it on a single-rank RCCL group, timed as "
+                         "one loop), all in this run on one GPU: an UPPER BOUND (no xGMI hops, no straggler).  allreduce_ms_single_rank is the same "
+                         "collective alone, back to back (host-bound enqueue; inside a step it hides behind the kernels).  "
+                         "implied_strong_scaling_8_with_ring_estimate = t(4096) / (t(512) + a documented "
+                         f"{RING_ALLREDUCE_MS_ESTIMATE * 1e3:.0f} us estimate of the exposed 8-rank ring all-reduce, SURVEY.md 8e); the 8-GPU "
                          "number itself is extra.strong_* of the driver's N = 8 line")
 
     # ---- parity of the timed configuration, in the line: the reference's OWN outputs for cfg2 (tests/golden/cfg2_lego_rand4096.npz: inputs,

@@ -107,22 +107,24 @@ class NeRFRunner:
     ``on_resample_fault`` ("raise" | "warn" | "ignore": what to do when ANY iteration since the last logging point met the reference's
     exit(0) condition of nerf.py:251-253 -- a training run that has died; the kernels record it in a sticky status word, the device path
     itself clamps the index and goes on.  Default "raise": the reference stops there too), ``distributed`` (None: data-parallel iff a
-    launcher started more than one rank; True: also with one rank -- rehearsals; False: never).
+    launcher started more than one rank; True: also with one rank -- rehearsals; False: never), ``overlap_allreduce`` (None: the
+    NERF_DP_OVERLAP environment variable, default off; True: reduce the early 83 % of the gradient bucket on a side stream beside the last
+    weight-gradient products).
 
     **Data-parallel training (BASELINE.json cfg3) and tile-sharded rendering (cfg5)**: under ``python -m torch.distributed.run
     --nproc-per-node N .../main.py`` every rank builds this runner on ``cuda:LOCAL_RANK`` (RANK / WORLD_SIZE / LOCAL_RANK are read from
     the environment before any GPU call), joins one RCCL group (backend "nccl"), starts from rank 0's weights and draws the SAME
     permutation from the same sampler seed; of every global ``batch_ray`` batch a rank gathers only its contiguous slice
     (``parallel.shard_bounds``; the global ray 0's near / far go to every rank: quirk Q6), runs forward + loss + backward with the
-    gradients written straight into one flat bucket, SUM-all-reduces it (the early 83 % beside the last weight-gradient products)
-    where the reference has ``loss.backward(); optimizer.step()`` (nerf.py:473-474) and takes the identical fused-Adam step.  Rank 0
+    gradients written straight into one flat bucket, SUM-all-reduces it (one collective behind the step; optionally the early 83 % beside
+    the last weight-gradient products) where the reference has ``loss.backward(); optimizer.step()`` (nerf.py:473-474) and takes the identical fused-Adam step.  Rank 0
     alone logs and writes checkpoints; ``display()`` deals the frames' reference batches out over the ranks with no collective in the
     data path and gathers the pixels afterwards."""
 
     def __init__(self, gpu=0, img_dir="../nerf_synthetic/lego/", results_path="./results/", ckpt_path="./checkpoint/", low_res=1,
                  total_iter=100000, batch_ray=400, learning=1e-3, lr_gamma=0.1, lr_milestone=(10, 200), n_coarse=64, n_fine=128,
                  data_type="sync", step=100, decay_end=200000, sched="EXP", continue_=False, *, datasets=None, log_every=None,
-                 seed=624, bf16_mlp=False, split_mlp=False, on_resample_fault="raise", distributed=None):
+                 seed=624, bf16_mlp=False, split_mlp=False, on_resample_fault="raise", distributed=None, overlap_allreduce=None):
         from . import nerf as _nerf
         from . import parallel as par
 
@@ -190,7 +192,12 @@ class NeRFRunner:
         self.bucket = par.GradBucket(self.model.network.parameters())
         if self.distributed:
             par.broadcast_parameters(self.model.network.parameters(), src=0)  # replicated weights, whatever each rank's RNG drew
-            self.bucket.enable_overlap()
+            # The early 83 % of the bucket (point_layer[0..7]) can be reduced on a side stream beside the last weight-gradient products
+            # (GradBucket.enable_overlap).  OPT-IN (overlap_allreduce=True or NERF_DP_OVERLAP=1): measured on a single-rank RCCL group the split
+            # launches and the two cross-stream hand-offs cost 46-62 us per step (scripts/dp_step_proxy.py) -- what an 8-rank ring all-reduce
+            # of these 2.27 MiB is priced at in the first place -- while ONE collective behind the step costs 1-6 us there.
+            if overlap_allreduce if overlap_allreduce is not None else os.environ.get("NERF_DP_OVERLAP") == "1":
+                self.bucket.enable_overlap()
 
         def ds(mode):
             if datasets is not None:

@@ -61,6 +61,34 @@ def test_bench_train_leg_with_rccl_allreduce():
     assert out["parity"]["pass"] is True and out["parity"]["split_mlp_vs_reference"]["pass"] is True
 
 
+@pytest.mark.timeout(900)
+def test_bench_default_line_carries_the_per_rank_proxy():
+    """The driver's command (`python bench.py`, N = 1; fewer steps here): one JSON line with roofline + parity and the per-rank proxy of the
+    8-GPU strong-scaling step -- a rank's 512-ray share and the reference's 400-ray batch, the train legs also as the MEASURED data-parallel
+    step (train_step + the flat SUM all-reduce behind it on a single-rank RCCL group) that `implied_strong_scaling_8` is computed from."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=_env(), timeout=860)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["dtype"] == "f32" and 0.0 < out["roofline"]["frac"] <= 1.0 and out["parity"]["pass"] is True
+    px = out["per_rank_proxy"]
+    for bs in ("512", "400"):
+        assert set(px[bs]) == {"forward_f32", "train_f32", "forward_bf16", "train_bf16", "forward_f32_split"}
+        for name, leg in px[bs].items():
+            assert leg["rays_per_step"] == int(bs) and leg["ms_per_step"] > 0 and 0.0 < leg["roofline_frac"] <= 1.0
+            if name.startswith("train"):
+                # the collective rides behind the step's kernels: the data-parallel step is the plain step plus a few microseconds
+                assert leg["ms_per_step"] * 0.9 < leg["dp_step_ms_single_rank"] < leg["ms_per_step"] + 0.08, (name, leg)
+    assert px["allreduce_ms_single_rank"] is not None and 0.0 < px["allreduce_ms_single_rank"] < 1.0
+    imp, ring = out["implied_strong_scaling_8"], out["implied_strong_scaling_8_with_ring_estimate"]
+    assert set(imp) == set(px["512"]) and all(1.0 < v <= 8.5 for v in imp.values()), imp
+    for name in imp:  # the ring estimate only ever lowers a train figure and leaves the inference figures alone
+        assert ring[name] <= imp[name] + 1e-9 and (name.startswith("train") or ring[name] == imp[name])
+    assert imp["train_f32"] == round(out["extra"]["train_f32"]["ms_per_step"] / px["512"]["train_f32"]["dp_step_ms_single_rank"], 2)
+
+
 def _run_ranks(n, out, extra=(), backend=None, timeout=500):
     """n ranks of tests/tools/dp_runner_rank.py under torch.distributed.run (n = 0: the plain single-process runner), fresh processes."""
     import socket
@@ -87,20 +115,21 @@ def _run_ranks(n, out, extra=(), backend=None, timeout=500):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("bf16", [False, True])
-def test_data_parallel_runner_single_rank_rccl_equals_plain_runner(tmp_path, bf16):
+@pytest.mark.parametrize("bf16,overlap", [(False, False), (True, False), (False, True), (True, True)])
+def test_data_parallel_runner_single_rank_rccl_equals_plain_runner(tmp_path, bf16, overlap):
     """NeRFRunner under a launcher.  One rank over a REAL RCCL group (the collective is the identity): the data-
-    parallel loop -- sharded sampler, gradients in the flat bucket, overlapped all-reduce, fused Adam on the views, rank 0 logging and
+    parallel loop -- sharded sampler, gradients in the flat bucket, the all-reduce (one collective behind the step, or with
+    overlap_allreduce=True its early part on a side stream behind the library's event), fused Adam on the views, rank 0 logging and
     checkpointing, display() through render_rows_sharded + gather_rows -- must leave bit-identical weights, losses and frames to the
-    plain single-process runner (same kernels, same order of the same batches) in fp32; bf16: see below."""
+    plain single-process runner (same kernels, same order of the same batches); bf16 WITH the overlap: see below."""
     import torch
 
     extra = ("--bf16",) if bf16 else ()
     plain = _run_ranks(0, str(tmp_path / "plain"), extra)
-    dp = _run_ranks(1, str(tmp_path / "dp1"), extra + ("--force-dist",))
+    dp = _run_ranks(1, str(tmp_path / "dp1"), extra + ("--force-dist",) + (("--overlap",) if overlap else ()))
     assert plain["distributed"] is False and dp["distributed"] is True and dp["ranks"] == 1 and dp["local_rays"] == 256
     assert len(dp["losses"]) == 6 and plain["losses"][0] == dp["losses"][0]
-    if not bf16:
+    if not (bf16 and overlap):
         assert plain["losses"] == dp["losses"]
         assert torch.equal(plain["weights"], dp["weights"])
         assert torch.equal(plain["frame"], dp["frame"])

@@ -2,7 +2,7 @@
 child process (the runner reads RANK / WORLD_SIZE / LOCAL_RANK from the environment before its first GPU call; nothing is re-exec'd).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        tests/tools/dp_runner_rank.py OUT_DIR [--bf16] [--iters K] [--batch B] [--force-dist]
+        tests/tools/dp_runner_rank.py OUT_DIR [--bf16] [--iters K] [--batch B] [--force-dist] [--overlap]
 
 N = 1: a real RCCL group (backend "nccl").  N = 2 on the one GPU of a test box: NERF_DIST_BACKEND=gloo (RCCL refuses two ranks on one
 device), both ranks on cuda:0 -- the same runner code, the collectives through the host.
@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--force-dist", action="store_true", help="join a process group also as a single rank")
+    ap.add_argument("--overlap", action="store_true", help="NeRFRunner(overlap_allreduce=True): early part of the bucket reduced on a side stream")
     args = ap.parse_args()
     if os.environ.get("NERF_DIST_BACKEND") == "gloo":
         os.environ["LOCAL_RANK"] = "0"  # every rank of the rehearsal on the box's one GPU
@@ -39,7 +40,7 @@ def main():
               total_iter=args.iters, batch_ray=args.batch, learning=1e-3, lr_gamma=0.1, lr_milestone=[10, 200], n_coarse=32, n_fine=64,
               data_type="sync", step=args.iters // 2, decay_end=10000, sched="EXP", datasets={"train": scene, "val": scene, "test": scene},
               log_every=1, bf16_mlp=args.bf16, on_resample_fault="warn")
-    run = P.NeRFRunner(continue_=False, distributed=True if args.force_dist else None, **kw)
+    run = P.NeRFRunner(continue_=False, distributed=True if args.force_dist else None, overlap_allreduce=True if args.overlap else None, **kw)
     losses = []
     wrote = []
     if run.rank == 0:
