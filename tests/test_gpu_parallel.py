@@ -86,7 +86,10 @@ def test_bench_default_line_carries_the_per_rank_proxy():
     assert set(imp) == set(px["512"]) and all(1.0 < v <= 8.5 for v in imp.values()), imp
     for name in imp:  # the ring estimate only ever lowers a train figure and leaves the inference figures alone
         assert ring[name] <= imp[name] + 1e-9 and (name.startswith("train") or ring[name] == imp[name])
-    assert imp["train_f32"] == round(out["extra"]["train_f32"]["ms_per_step"] / px["512"]["train_f32"]["dp_step_ms_single_rank"], 2)
+    assert imp["train_f32"] == round(px["4096"]["train_f32"]["ms_per_step"] / px["512"]["train_f32"]["dp_step_ms_single_rank"], 2)
+    assert imp["forward_bf16"] == round(px["4096"]["forward_bf16"]["ms_per_step"] / px["512"]["forward_bf16"]["ms_per_step"], 2)
+    for name, leg in px["4096"].items():  # the same step with and without the library's kernel events: within a few per cent
+        assert 0.9 * leg["ms_per_step_with_kernel_events"] < leg["ms_per_step"] < 1.05 * leg["ms_per_step_with_kernel_events"], (name, leg)
 
 
 def _run_ranks(n, out, extra=(), backend=None, timeout=500):
