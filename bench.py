@@ -46,6 +46,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0                   # same table: bf16 matrix, dens
 PEAK_HBM_GBS = 8000.0
 N_PARAMS = 593_924
 FUSED_TRAIN_STEP = True  # train legs: NeRFModel.train_step (one library call per step); --autograd-step times the three-call autograd path
+OVERLAP_ALLREDUCE = False  # set by main(): --overlap / NERF_DP_OVERLAP=1
 PROXY_WARMUP_S = 0.2  # untimed run-in of every per_rank_proxy leg (run_leg: warmup_seconds)
 RING_ALLREDUCE_MS_ESTIMATE = 0.060  # 30-60 us for the un-overlapped 2.27 MiB SUM all-reduce on an 8-GPU xGMI ring (upper end)
 
@@ -495,8 +496,11 @@ def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong)
                                "note": "measured HBM traffic of forward-with-saves (x2), dX chain (x2) and the weight-gradient phase, scaled to this run's batch"}
     if leg.train:
         rep["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
-        rep["allreduce"] = (f"SUM all-reduce of {N_PARAMS} fp32 gradients (2.27 MiB) over RCCL, world {world}, in two parts: point_layer[0..7] on a side stream "
-                            "behind the library's event (beside the last weight-gradient products), the rest behind the backward; allreduce_ms = the exposed part"
+        rep["allreduce"] = ((f"SUM all-reduce of {N_PARAMS} fp32 gradients (2.27 MiB) over RCCL, world {world}, " +
+                             ("in two parts: point_layer[0..7] on a side stream behind the library's event (beside the last weight-gradient products), the "
+                              "rest behind the backward; allreduce_ms = the exposed part" if OVERLAP_ALLREDUCE else
+                              "ONE collective behind the step (--overlap / NERF_DP_OVERLAP=1: its early 83 % beside the last weight-gradient products); "
+                              "allreduce_ms = HIP events around it in a short second run"))
                             if ar_ms is not None
                             else "none (single rank without a process group)")
     return rep
@@ -648,6 +652,8 @@ def main():
     # per step (scripts/dp_step_proxy.py), as much as an 8-rank ring all-reduce of 2.27 MiB is priced at
     if dist is not None and (args.overlap or os.environ.get("NERF_DP_OVERLAP") == "1"):
         bucket.enable_overlap()
+        global OVERLAP_ALLREDUCE
+        OVERLAP_ALLREDUCE = True
 
     def shard(full, lo, hi):
         """Device inputs of rays [lo, hi) of a batch; the model is told its batch size and the GLOBAL ray 0's (near, far): its
