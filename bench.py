@@ -21,7 +21,9 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     400 rays, conf/lego.ini:7) + a single-rank RCCL all-reduce, and reports `implied_strong_scaling_8 = t(4096) / (t(512) + allreduce)`.
   * `parity`: the timed configuration rendered once on the golden cfg2 fixture against the REFERENCE's own outputs (max-rel, PSNR).
   * `n_gpus` in the line is `dist.get_world_size()`, not the flag.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line of at most 4 KB (compact_line: the contract's keys, `roofline`, `cpu_baseline`, `parity`, a few scalars of the other
+legs); the full record -- `extra`, `roofline_phases`, `per_rank_proxy`, `frame_render`, every note -- goes to bench_extra.json beside this
+script (--side-file) and, prefixed "bench_extra: ", to stderr.
 """
 import argparse
 import json
@@ -546,6 +548,94 @@ def parity_block(model, dev):
     return out
 
 
+
+# --------------------------------------------------------------------------------------------------------------------
+# the result line: compact (<= LINE_LIMIT bytes) for the driver; the full record goes to bench_extra.json beside this script
+# --------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+SIDE_FILE = "bench_extra.json"
+
+
+def write_side_file(full, explicit=None):
+    """The full record of the run (every leg, roofline phases, per-rank proxy, frame render, notes) as JSON: at `explicit` (--side-file), else
+    beside bench.py and -- when that directory exists, so that it travels back from a gpurun box -- under gpurun_out/.  Returns the first
+    path written, or None (the record is on stderr as well)."""
+    path = None
+    targets = [explicit] if explicit else [os.path.join(ROOT, SIDE_FILE)] + (
+        [os.path.join(ROOT, "gpurun_out", SIDE_FILE)] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])
+    for t in targets:
+        try:
+            with open(t, "w") as f:
+                json.dump(full, f, indent=1)
+            path = path or t
+        except OSError as ex:
+            print(f"bench.py: could not write {t}: {ex}", file=sys.stderr)
+    return path
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full, side_path=None):
+    """The ONE line the driver parses: the contract's keys, `roofline` and `cpu_baseline` as prompt section 4 defines them, the parity of
+    the timed configuration and a handful of scalars of the other legs.  No notes, no per-kernel tables, no nested legs: those are in the
+    side file.  Free-text values are cut to 160 characters; the result is asserted to fit LINE_LIMIT bytes."""
+
+    def cut(v, n=160):
+        return v if not isinstance(v, str) or len(v) <= n else v[: n - 3] + "..."
+
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line["metric"] = cut(line.get("metric"), 120)
+    cfg = full.get("config", {})
+    line["config"] = {k: cut(cfg[k]) for k in ("workload", "rays_per_step_per_gpu", "mode", "weights", "parallelism") if k in cfg}
+    line["roofline"] = {k: cut(v, 100) for k, v in _pick(full.get("roofline", {}), (
+        "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "traffic", "traffic_source", "kernel", "avg_launch_ms", "launches")).items()}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {k: cut(v, 120) for k, v in _pick(cb, ("value", "unit", "cores", "kind", "sample", "value_at_8_threads")).items()}
+        if isinstance(cb.get("train"), dict):
+            line["cpu_baseline"]["train_value"] = cb["train"].get("value")
+        line["gpu_over_cpu"] = full.get("gpu_over_cpu")
+    par = full.get("parity")
+    if isinstance(par, dict):
+        line["parity"] = _pick(par, ("max_rel_C_coarse", "max_rel_C_fine", "psnr_vs_ref_db", "pass", "error"))
+        if "error" in line["parity"]:
+            line["parity"]["error"] = cut(line["parity"]["error"])
+    if "allreduce_ms" in full:
+        line["allreduce_ms"] = full["allreduce_ms"]
+    ex = full.get("extra", {})
+    for name in ("train_f32", "forward_bf16", "train_bf16", "forward_f32_split"):
+        if name in ex:
+            line[name + "_rays_per_s"] = ex[name].get("value")
+    for name in ("train_f32", "train_bf16"):  # the N > 1 strong-scaling legs: one 4096-ray batch split over the ranks
+        if "strong_" + name in ex:
+            line["strong_" + name + "_rays_per_s"] = ex["strong_" + name].get("value")
+            line["strong_" + name + "_allreduce_ms"] = ex["strong_" + name].get("allreduce_ms")
+    if "strong_forward_f32" in ex:
+        line["strong_forward_f32_rays_per_s"] = ex["strong_forward_f32"].get("value")
+    if "strong_forward_bf16" in ex:
+        line["strong_forward_bf16_rays_per_s"] = ex["strong_forward_bf16"].get("value")
+    ph = full.get("extra", {}).get("train_f32", {}).get("roofline_phases") or full.get("roofline_phases")
+    if isinstance(ph, dict):
+        line["train_f32_phase_frac"] = {k: v.get("frac") for k, v in ph.items() if isinstance(v, dict)}
+    imp = full.get("implied_strong_scaling_8")
+    if isinstance(imp, dict) and imp:
+        line["implied_strong_scaling_8_min"] = min(imp.values())
+        ring = full.get("implied_strong_scaling_8_with_ring_estimate")
+        if isinstance(ring, dict) and ring:
+            line["implied_strong_scaling_8_with_ring_estimate_min"] = min(ring.values())
+    if side_path is not None:
+        line["side_file"] = os.path.basename(side_path)
+    n = len(json.dumps(line, separators=(",", ":")))
+    if n > LINE_LIMIT:  # never print a line the driver cannot take: drop the optional scalars, keep the contract + roofline + cpu_baseline
+        for k in [k for k in line if k.endswith("_rays_per_s") or k.startswith("implied_") or k in ("train_f32_phase_frac", "parity", "gpu_over_cpu")]:
+            line.pop(k)
+        n = len(json.dumps(line, separators=(",", ":")))
+    assert n <= LINE_LIMIT, f"bench.py: result line is {n} bytes (> {LINE_LIMIT})"
+    return line
+
+
 # --------------------------------------------------------------------------------------------------------------------
 def dry_main(args):
     """CPU rehearsal of the N-rank plumbing (tests/test_bench_launch.py): gloo ranks, the same fence / MAX reduction /
@@ -597,6 +687,8 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="N > 1 train legs: overlap the early part of the all-reduce with the last weight-gradient products")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the leg named by --mode/--mlp (profiling runs)")
+    ap.add_argument("--side-file", default=None, help="where the full record goes (default: bench_extra.json beside this script); the stdout line "
+                                                      "is the compact <= 4 KB form of it")
     ap.add_argument("--dry", action="store_true", help="CPU rehearsal of the launcher + process group over gloo (no kernels; tests only)")
     args = ap.parse_args()
 
@@ -867,7 +959,11 @@ def main():
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
+        # the driver reads ONE short line (BENCH_r04: a 21 KB line was not taken); everything else goes to the side file and to stderr
+        side = write_side_file(out, args.side_file)
+        line = compact_line(out, side)
+        print("bench_extra: " + json.dumps(out), file=sys.stderr, flush=True)  # (prefixed: never mistaken for the result line)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -17,6 +17,7 @@ def test_gpus_flag_launches_that_many_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout  # ONE JSON line on stdout
+    assert len(lines[0]) < 4096
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["flag_gpus"] == 2 and out["steps"] == 3 and out["dry"] is True
 
@@ -58,3 +59,61 @@ def test_train_traffic_lookup_matches_the_shipped_kernel_names():
     for keys in (["k_field_fwd_bf16<true, 8>"], ["k_field_bwd_bf16<true, 8>", "k_field_bwd_bf16<false, 8>"]):
         assert bench.read_traffic(bf_train, keys) is not None, keys
     assert bench.read_traffic(bf_fwd, ["k_field_fwd_bf16x<2, 8>"]) is not None
+
+
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline")
+
+
+def test_result_line_stays_under_4_kb_on_a_full_record():
+    """BENCH_r04.json: the driver did not take a 21 KB line.  compact_line() of a REAL full record (round 4's N = 1 default run, committed as
+    profiles/r04_bench_default.json) and of its N = 8 form (five strong_* legs added, long free-text values) must stay below 4 KB and keep
+    the contract's keys, `roofline` and `cpu_baseline` with the fields the contract names."""
+    bench = _bench_module()
+    with open(os.path.join(ROOT, "profiles", "r04_bench_default.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000  # the record that broke the driver's parse
+    line = bench.compact_line(full, "/somewhere/bench_extra.json")
+    s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < 4096, len(s)
+    for k in CONTRACT_KEYS:
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert set(line["config"]) == {"workload", "rays_per_step_per_gpu", "mode", "weights", "parallelism"} and "model" not in line["config"]
+    assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"] <= 1.0
+    assert line["parity"]["pass"] is True and line["side_file"] == "bench_extra.json"
+    assert line["train_f32_rays_per_s"] == full["extra"]["train_f32"]["value"]
+    assert line["implied_strong_scaling_8_min"] == min(full["implied_strong_scaling_8"].values())
+    # the N = 8 shape of the record: strong_* legs beside the weak ones, an all-reduce, pathological free text
+    big = json.loads(json.dumps(full))
+    for name in ("forward_f32", "train_f32", "forward_bf16", "train_bf16", "forward_f32_split"):
+        src = big["extra"].get(name, big["extra"]["train_f32"])
+        big["extra"]["strong_" + name] = dict(src, allreduce_ms=0.0612)
+    big["n_gpus"], big["allreduce_ms"] = 8, 0.0588
+    big["config"]["workload"] = "w" * 5000
+    big["roofline"]["kernel"] = "k" * 5000
+    big["cpu_baseline"]["sample"] = "s" * 5000
+    big["metric"] = "m" * 5000
+    s8 = json.dumps(bench.compact_line(big, None), separators=(",", ":"))
+    assert len(s8) < 4096, len(s8)
+    l8 = json.loads(s8)
+    assert l8["strong_train_bf16_allreduce_ms"] == 0.0612 and l8["allreduce_ms"] == 0.0588 and l8["n_gpus"] == 8
+
+
+def test_side_file_holds_the_full_record(tmp_path):
+    bench = _bench_module()
+    with open(os.path.join(ROOT, "profiles", "r04_bench_default.json")) as f:
+        full = json.load(f)
+    p = bench.write_side_file(full, str(tmp_path / "x.json"))
+    with open(p) as f:
+        assert json.load(f) == full

@@ -28,18 +28,38 @@ def test_train_step_sharded_over_rccl_single_rank():
 
 
 @pytest.mark.timeout(900)
-def test_bench_train_leg_with_rccl_allreduce():
-    """bench.py's data-parallel train leg with a real (1-rank) RCCL group: one JSON line, n_gpus from the process group, the
-    all-reduce measured, and every extra leg present with its own roofline block."""
-    env = _env()
-    env["BENCH_FORCE_DIST"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                       capture_output=True, text=True, env=env, timeout=860)
+def _bench(args, env, tmp_path):
+    """bench.py as the driver runs it: ONE stdout line of at most 4 KB (the compact record) + the full record in the side file."""
+    side = os.path.join(str(tmp_path), "bench_extra.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--side-file", side], capture_output=True, text=True, env=env, timeout=860)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    assert len(lines[0]) < 4096, len(lines[0])  # BENCH_r04: a 21 KB line was not taken by the driver
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches"}
+    assert "bench_extra: {" in r.stderr  # the full record is on stderr as well
+    with open(side) as f:
+        full = json.load(f)
+    for k in ("metric", "value", "ms_per_step", "n_gpus", "dtype"):
+        assert line[k] == full[k], k
+    assert line["roofline"]["frac"] == full["roofline"]["frac"]
+    return line, full
+
+
+@pytest.mark.timeout(900)
+def test_bench_train_leg_with_rccl_allreduce(tmp_path):
+    """bench.py's data-parallel train leg with a real (1-rank) RCCL group: one compact JSON line, n_gpus from the process group, the
+    all-reduce measured, and (side file) every extra leg present with its own roofline block."""
+    env = _env()
+    env["BENCH_FORCE_DIST"] = "1"
+    line, out = _bench(["--mode", "train", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env, tmp_path)
     assert out["n_gpus"] == 1 and out["config"]["mode"] == "train"
+    assert line["allreduce_ms"] == out["allreduce_ms"] and line["parity"]["pass"] is True
+    assert line["strong_train_bf16_rays_per_s"] == out["extra"]["strong_train_bf16"]["value"]
     assert out["allreduce_ms"] is not None and 0.0 < out["allreduce_ms"] < 50.0
     assert set(out["roofline_phases"]) == {"forward_with_saves", "dx_chain", "dw"}
     # the weak legs and -- the code path of the driver's N = 8 line -- the strong-scaling form of all four legs (here: one rank = the whole batch)
@@ -62,17 +82,15 @@ def test_bench_train_leg_with_rccl_allreduce():
 
 
 @pytest.mark.timeout(900)
-def test_bench_default_line_carries_the_per_rank_proxy():
-    """The driver's command (`python bench.py`, N = 1; fewer steps here): one JSON line with roofline + parity and the per-rank proxy of the
-    8-GPU strong-scaling step -- a rank's 512-ray share and the reference's 400-ray batch, the train legs also as the MEASURED data-parallel
-    step (train_step + the flat SUM all-reduce behind it on a single-rank RCCL group) that `implied_strong_scaling_8` is computed from."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
-                       capture_output=True, text=True, env=_env(), timeout=860)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+def test_bench_default_line_carries_the_per_rank_proxy(tmp_path):
+    """The driver's command (`python bench.py`, N = 1; fewer steps here): one compact JSON line with roofline + parity; the side file holds
+    the per-rank proxy of the 8-GPU strong-scaling step -- a rank's 512-ray share and the reference's 400-ray batch, the train legs also as the
+    MEASURED data-parallel step (train_step + the flat SUM all-reduce behind it on a single-rank RCCL group) that `implied_strong_scaling_8` is
+    computed from."""
+    line, out = _bench(["--steps", "5", "--warmup", "2", "--no-cpu-baseline"], _env(), tmp_path)
     assert out["n_gpus"] == 1 and out["dtype"] == "f32" and 0.0 < out["roofline"]["frac"] <= 1.0 and out["parity"]["pass"] is True
+    assert line["parity"]["pass"] is True and line["implied_strong_scaling_8_min"] == min(out["implied_strong_scaling_8"].values())
+    assert line["train_f32_rays_per_s"] == out["extra"]["train_f32"]["value"] and line["train_bf16_rays_per_s"] == out["extra"]["train_bf16"]["value"]
     px = out["per_rank_proxy"]
     for bs in ("512", "400"):
         assert set(px[bs]) == {"forward_f32", "train_f32", "forward_bf16", "train_bf16", "forward_f32_split"}
