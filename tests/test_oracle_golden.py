@@ -59,6 +59,39 @@ def test_gradients(oracle, name):
             assert l2_rel(v.flatten()[::97], g["gslice_" + k]) < tol, k
 
 
+@pytest.mark.parametrize("name", ["dec_cfg1_lego_crop32_r32", "dec_cfg4_fern_r32"])
+def test_oracle_reproduces_the_references_decisions(oracle, name):
+    """tests/golden/make_decisions_golden.py: the reference's torch.sort indices (nerf.py:308), index_fine (nerf.py:248) and ReLU sign bits
+    (nerf.py:107-119), recorded inside the run that produced the stored gradients.  On the generating host class the oracle takes the same
+    decisions bit for bit and lands on the same gradients to 1e-5; elsewhere (another BLAS) nearly all decisions and a band."""
+    g = load_golden(name)
+    row, col, pb, K, Ct = golden_inputs(g)
+    Nc, Nf = int(g["Nc"]), int(g["Nf"])
+    w = oracle.make_weights(int(g["seed"]), bool(g["sharp"]))
+    p = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    st = {}
+    Cc, Cf = oracle.render(p, row, col, pb, K, Nc, Nf, stages=st)
+    loss = oracle.ray_loss(Cc, Cf, Ct)
+    loss.backward()
+    same_host = str(g["meta_host"]) == oracle.host_fingerprint()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    perm, k = st["perm"].numpy(), st["k"].numpy()
+    f_p, _ = oracle.frequencies()
+    with torch.no_grad():
+        _, _, hid, _, c = oracle.mlp(w, oracle.encode(st["pts_f"].detach(), f_p), st["gd"][:, None, :].expand(-1, Nf, -1), return_hidden=True)
+    relu_f = np.stack([np.packbits((h > 0).numpy().astype(np.uint8), axis=-1, bitorder="little") for h in hid])
+    if same_host:
+        assert np.array_equal(perm, g["sort_index"]) and np.array_equal(k, g["index_fine"]) and np.array_equal(relu_f, g["relu_f"])
+        for kk, v in p.items():
+            assert l2_rel(v.grad, g["grad_" + kk]) < 1e-5, kk
+    else:
+        assert float((perm[:, :, 0] == g["sort_index"][:, :, 0]).mean()) > 0.999  # (the depth channel has no near-ties)
+        assert float((k == g["index_fine"]).mean()) > 0.99
+        assert float(np.unpackbits(relu_f ^ g["relu_f"]).mean()) < 1e-3
+        for kk, v in p.items():
+            assert l2_rel(v.grad, g["grad_" + kk]) < 0.3, kk
+
+
 def test_frequencies_bits(oracle):
     """quirk Q3: non-integer octaves; bit patterns baked into csrc/common.h."""
     fp, fd = oracle.frequencies()
