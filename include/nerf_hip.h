@@ -17,6 +17,11 @@
  *     (thread-local).  The library never aborts the process.
  *   - threading: re-entrant per (device, stream); calls sharing a workspace must be ordered
  *     on one stream.
+ *   - stream capture: NOT replay-safe.  Every nerf_hip_forward / nerf_hip_train_step bakes a per-call token into
+ *     kernel arguments (the in-launch hand-off of the bf16-MLP preparation, the generation stamp of the status word);
+ *     a captured graph replayed later would present last replay's token.  Enqueue the calls afresh.
+ *   - workspace: the caller zeroes its first 256 bytes (the status region) ONCE after allocating it; the library
+ *     never clears words 32..63 of that region on its own (sticky flags, nerf_hip_read_status_sticky).
  *   - all floating point data is IEEE fp32 ("f32"), row-major.
  *
  * Weight order (`weights24`, HOST array of 24 DEVICE pointers) = NeRFModel.network.parameters()
@@ -72,9 +77,13 @@ enum {
 /* status word bits (nerf_hip_read_status) */
 enum {
   NERF_HIP_STATUS_RESAMPLE_INDEX = 1 << 0, /* the condition on which nerf.py:251-253 calls exit(0) (quirk Q7) */
-  NERF_HIP_STATUS_PREP_TIMEOUT = 1 << 1,   /* STICKY word only: a block of the one-launch preparation of a bf16-MLP call gave up waiting for
-                                              the weight fold (never seen in practice: the wait is bounded so that a fault cannot hang the GPU;
-                                              the results of that call are wrong) */
+  NERF_HIP_STATUS_PREP_TIMEOUT = 1 << 1,   /* bf16-MLP calls only: a block of the one-launch preparation gave up waiting for the weight fold
+                                              of the SAME launch (bounded wait; relies on in-order workgroup dispatch, which gfx950 provides but
+                                              HIP does not promise -- NERF_PREP_BF16=0 in the environment selects separate launches instead).
+                                              The packed weight image of that call is then POISONED with NaN: its C_coarse / C_fine / loss /
+                                              gradients are NaN, never plausible wrong numbers.  Reported by nerf_hip_read_status for that call
+                                              and for every later call that reuses the image (NERF_HIP_WEIGHTS_UNCHANGED), and in the sticky
+                                              word.  Never seen outside the fault-injection test. */
 };
 
 /* Limits of this build: 2 <= B, 2 <= Nc <= 1024, 1 <= Nf <= 1024, Nc + Nf <= 2048. */

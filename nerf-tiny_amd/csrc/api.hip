@@ -891,12 +891,17 @@ int nerf_hip_ray_loss(const float* C_coarse, const float* C_fine, const float* C
 int nerf_hip_read_status(const void* ws, size_t ws_bytes, uint32_t* status, void* stream) {
   if (!ws || !status || ws_bytes < 256) return fail(NERF_HIP_ERR_ARG, "null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  uint32_t w[4] = {0, 0, 0, 0};
+  uint32_t w[STATUS_STICKY_WORD + 3];
+  memset(w, 0, sizeof(w));
   HIP_TRY(hipMemcpyAsync(w, ws, sizeof(w), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   // legacy scheme: word 0 (zeroed by the call's first kernel); stamped scheme (common.h STATUS_*): the flags count only with this call's stamp
   if (w[STATUS_SCHEME_WORD] == 1u) *status = ((w[STATUS_STAMPED_WORD] >> 8) == w[STATUS_GEN_WORD]) ? (w[STATUS_STAMPED_WORD] & 0xffu) : 0u;
-  else *status = w[0];
+  else *status = w[0] & ~(uint32_t)NERF_HIP_STATUS_PREP_TIMEOUT;
+  // the one-launch preparation of the bf16-MLP calls (prep_bf16.hip): the weight image now in this workspace was packed by the call whose
+  // token is word 34; word 33 = the last call whose wait for the fold timed out.  Equal and non-zero: the image is POISONED (NaN), and so is
+  // every call that used or reuses it (NERF_HIP_WEIGHTS_UNCHANGED) until the next packing call
+  if (w[STATUS_STICKY_WORD + 1] != 0u && w[STATUS_STICKY_WORD + 1] == w[STATUS_STICKY_WORD + 2]) *status |= NERF_HIP_STATUS_PREP_TIMEOUT;
   return NERF_HIP_OK;
 }
 

@@ -54,15 +54,16 @@ __device__ __forceinline__ unsigned alive_bits(const f32x16& A) {
   return ~bits & 0xffffu;
 }
 
-// The lane id, produced AT this program point (volatile: never merged with an earlier copy, which would have to stay alive -- or be
-// parked in scratch -- across the stream): what the epilogues of the stream kernels form their addresses from.
-// The s_nops in front: the compiler may hand the asm a destination register that overlaps a DEAD row of the accumulator of an MFMA still in
-// flight, and its hazard recognizer does not look inside the asm -- the MFMA's late write then clobbers the lane id (seen in round 4: every
-// lane of an epilogue stored to sample 0).  20 wait states cover the longest MFMA's write-after-write window whatever the allocation.
+// The lane id, produced AT this program point: what the epilogues of the stream kernels form their addresses from.  The zero the count starts
+// from is an SGPR made opaque by an empty asm, so the v_mbcnt pair cannot be merged with an earlier copy (which would have to stay alive --
+// or be parked in scratch -- across the stream), yet the pair itself is ordinary compiler-issued code: the hazard recognizer sees its
+// destination and keeps it clear of the accumulator rows of an MFMA still in flight.  (Round 4's form was an `asm volatile` v_mbcnt whose
+// destination the allocator once placed on a dead row of an in-flight MFMA's accumulator -- every lane of an epilogue then stored to sample
+// 0 -- held off by 20 s_nop wait states the recognizer could not check.)
 __device__ __forceinline__ unsigned lane_id_here() {
-  unsigned l;
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3\n\tv_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
+  unsigned z = 0u;
+  asm volatile("" : "+s"(z));
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
 }
 
 template <int N>

@@ -211,12 +211,13 @@ class DeviceRays:
             return torch.randperm(self.num_pix, device=self.device, generator=self.gen)
         return torch.arange(self.num_pix, device=self.device)
 
-    def epoch(self, batch_ray: int, shuffle: bool = True):
+    def epoch(self, batch_ray: int, shuffle: bool = True, first_batch: int = 0):
+        """`first_batch`: skip that many batches of the epoch's order (a resumed run continues the interrupted epoch)."""
         order = self.epoch_order(shuffle)
-        for s in range(0, self.num_pix - batch_ray + 1, batch_ray):  # drop_last=True
+        for s in range(first_batch * batch_ray, self.num_pix - batch_ray + 1, batch_ray):  # drop_last=True
             yield self.gather(order[s:s + batch_ray])
 
-    def epoch_sharded(self, batch_ray: int, rank: int, world: int, shuffle: bool = True):
+    def epoch_sharded(self, batch_ray: int, rank: int, world: int, shuffle: bool = True, first_batch: int = 0):
         """One epoch of a data-parallel trainer: every rank draws the SAME order (same seed) and gathers only its contiguous slice
         [lo, hi) of every global `batch_ray` batch (parallel.shard_bounds).  Yields (row, col, pix_val, poses_bound, pic, ray0) where
         ray0 = (near, far) of the GLOBAL batch's ray 0 as host floats -- the one cross-ray term of the path (quirk Q6, nerf.py:233); the
@@ -231,6 +232,8 @@ class DeviceRays:
         first_pic = (order[0:starts[-1] + 1:batch_ray] // (self.height * self.width)).cpu()
         nf = self.poses[:, 15:17].cpu()[first_pic]  # [n_batches, 2] fp32, exactly the values the kernels see (nerf.py:338 cast)
         for b, s in enumerate(starts):
+            if b < first_batch:  # (a resumed run continues the interrupted epoch)
+                continue
             yield (*self.gather(order[s + lo:s + hi]), (float(nf[b, 0]), float(nf[b, 1])))
 
     def __len__(self):

@@ -335,12 +335,22 @@ class NeRFModel(nn.Module):
         """Did the most recent forward meet the reference's exit condition -- a ray whose resampling index falls outside [0, Nf-1], i.e.
         whose coarse weights all vanished (nerf.py:251-253: banner + exit(0))?  The device path clamps the index and goes on; this reads
         the status word the kernels left (ONE host sync)."""
+        return bool(self.read_status() & _abi.STATUS_RESAMPLE_INDEX)
+
+    def read_status(self) -> int:
+        """The status word of the most recent call on this model (``nerf_hip_read_status``: ONE host sync).  Raises ``NerfHipError`` on
+        STATUS_PREP_TIMEOUT -- the one-launch preparation of a bf16-MLP call gave up waiting for its weight fold, the packed weight image
+        is poisoned with NaN and so are the outputs of every call that used it (csrc/prep_bf16.hip) -- so that no caller renders or trains
+        on from there."""
         ws = self._last_ws
         if ws is None:
-            return False
+            return 0
         st = C.c_uint32(0)
         _abi.check(_abi.lib().nerf_hip_read_status(ws.data_ptr(), ws.numel(), C.byref(st), torch.cuda.current_stream(ws.device).cuda_stream))
-        return bool(st.value & _abi.STATUS_RESAMPLE_INDEX)
+        if st.value & _abi.STATUS_PREP_TIMEOUT:
+            raise _abi.NerfHipError("a bf16-MLP call's one-launch preparation gave up waiting for the weight fold (prep_bf16.hip): the packed weight "
+                                    "image is poisoned, the outputs of that call are NaN")
+        return int(st.value)
 
     def resample_fault_since(self, clear: bool = True) -> bool:
         """Did ANY forward on the current workspaces meet that condition since the last call that cleared the record?  The kernels OR the
@@ -396,6 +406,8 @@ class NeRFModel(nn.Module):
                     C_f[s - lo:e - lo] = f[: e - s]
         finally:
             self.ray0_near_far, self._ws_capacity = prev_ray0, prev_cap
+        if getattr(self, "bf16_mlp", False):
+            self.read_status()  # a frame is not handed out on a poisoned weight image (raises on STATUS_PREP_TIMEOUT; one sync per frame)
         return C_c, C_f
 
 

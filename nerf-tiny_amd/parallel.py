@@ -141,9 +141,15 @@ def train_step_local(model, bucket: GradBucket, row, col, poses_bound, K_inv, C_
     parts with `bucket.enable_overlap()`), placed where the reference has ``loss.backward(); optimizer.step()`` (nerf.py:473-474).
     Returns this rank's (C_coarse, C_fine, local loss); every rank then holds the full-batch gradient in p.grad (views of `bucket.flat`)."""
     prev_ray0, prev_bucket = model.ray0_near_far, model.grad_bucket
+    # `model.check_resample` (mimic nerf.py:251-253: raise where the reference exit(0)s) is a RANK-LOCAL raise; taken before the
+    # collective it would leave the other ranks blocked in all_reduce.  The check is therefore made AFTER the all-reduce, its
+    # outcome MAX-reduced, and every rank raises together.
+    check = bool(getattr(model, "check_resample", False))
     model.ray0_near_far = ray0
     model.grad_bucket = bucket
     try:
+        if check:
+            model.check_resample = False
         if hasattr(model, "train_step"):  # forward + loss + backward in ONE library call (same kernels, same bits)
             C_c, C_f, loss = model.train_step(row, col, poses_bound, K_inv, C_true)
         else:
@@ -152,10 +158,22 @@ def train_step_local(model, bucket: GradBucket, row, col, poses_bound, K_inv, C_
             loss.backward()
     finally:
         model.ray0_near_far, model.grad_bucket = prev_ray0, prev_bucket
-    if world > 1 or (dist.is_available() and dist.is_initialized()):
+        if check:
+            model.check_resample = True
+    grouped = world > 1 or (dist.is_available() and dist.is_initialized())
+    if grouped:
         bucket.allreduce_sum(group)
     else:
         bucket.consume()  # a single process without a group: p.grad (the views) go straight to the optimizer
+    if check:
+        fault = bool(model.resample_fault())
+        if grouped:
+            fault = allreduce_host_scalars([1.0 if fault else 0.0], dist.ReduceOp.MAX, row.device if row.device.type == "cuda" else loss.device,
+                                           group)[0] > 0.0
+        if fault:
+            from .nerf import ResampleIndexError
+
+            raise ResampleIndexError("resample index outside [0, Nf-1] on at least one rank (the reference exit(0)s here, nerf.py:251-253)")
     return C_c, C_f, loss
 
 

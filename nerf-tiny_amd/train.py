@@ -52,6 +52,19 @@ class FusedAdam(torch.optim.Optimizer):
             o += p.numel()
         self._step = int(self.state[ps[0]]["step"])
 
+    def flat_state(self) -> dict:
+        """What a resume needs, flat (parameters() order): {"step", "exp_avg" [593,924], "exp_avg_sq" [593,924]} on the host."""
+        return {"step": int(self._step), "exp_avg": self._m.detach().cpu().clone(), "exp_avg_sq": self._v.detach().cpu().clone()}
+
+    def load_flat_state(self, st: dict) -> None:
+        if st["exp_avg"].numel() != self._m.numel() or st["exp_avg_sq"].numel() != self._v.numel():
+            raise ValueError("optimizer state of another architecture")
+        self._m.copy_(st["exp_avg"].to(self._m.device))
+        self._v.copy_(st["exp_avg_sq"].to(self._v.device))
+        self._step = int(st["step"])
+        for p in self.param_groups[0]["params"]:
+            self.state[p]["step"] = torch.tensor(float(self._step))
+
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
@@ -183,7 +196,7 @@ class NeRFRunner:
                     last_iter, last_ckpt = it, f
         if last_ckpt is not None:
             self.model = torch.load(last_ckpt, weights_only=False, map_location=self.device).to(self.device)
-            self.model.batch_ray = self.local_rays  # (the checkpoint is rank 0's whole module: its batch size was rank 0's slice)
+            self.model.batch_ray = self.local_rays  # (the checkpoint holds the CONFIGURED batch size; this rank's kernels see its slice)
         self.last_iter = last_iter
         self.model.bf16_mlp = bool(bf16_mlp)  # an attribute, not part of the checkpoint format: set after a resume too
         self.model.split_mlp = bool(split_mlp)
@@ -216,6 +229,13 @@ class NeRFRunner:
 
         self.optimizer = FusedAdam([{"params": list(self.model.network.parameters()), "initial_lr": learning}], lr=learning,
                                    betas=(0.9, 0.999), eps=1e-7)
+        # resume: "<time>_<iter>.opt" beside the checkpoint (written by this runner; absent for a reference-written checkpoint) restores
+        # Adam's moments / step and the sampler's position, so that N iterations == k + resume + (N - k) bit for bit in fp32
+        self._resume_sampler = None
+        if last_ckpt is not None:
+            st = self._load_opt_state(last_ckpt)
+            if st is not None:
+                self._resume_sampler = (st.get("mode", "train"), st["sampler"])
         if sched == "EXP":  # nerf.py:426, including its post-decay_end multiplier lr_gamma * learning
             self.scheduler = torch.optim.lr_scheduler.LambdaLR(
                 self.optimizer, lr_lambda=lambda it: lr_gamma ** (it / decay_end) if it < decay_end else lr_gamma * learning,
@@ -224,17 +244,45 @@ class NeRFRunner:
             self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, list(lr_milestone), lr_gamma, last_epoch=self.last_iter)
 
     # ----- the two collectives of the logging point (data-parallel runs only; every rank reaches them at the same iterations) -----
-    def _global_loss_and_fault(self, loss, fault: bool):
+    def _global_loss_and_fault(self, loss, fault: bool, error: bool = False):
+        """-> (global loss, any rank's resample fault, any rank's error).  ONE SUM and ONE MAX collective; a rank-local error (a raised
+        NerfHipError at the logging point) travels as a flag through the MAX so that EVERY rank raises afterwards -- a rank that left the
+        loop alone would leave the others blocked in the next all_reduce until the RCCL timeout."""
         lv = float(loss.detach())
         if not self.distributed:
-            return lv, fault
+            return lv, fault, error
         import torch.distributed as dist
 
         from . import parallel as par
 
         total = par.allreduce_host_scalars([lv], dist.ReduceOp.SUM, self.device, self.group)[0]  # the loss is a SUM over rays (nerf.py:328-331)
-        any_fault = par.allreduce_host_scalars([1.0 if fault else 0.0], dist.ReduceOp.MAX, self.device, self.group)[0] > 0.0
-        return total, any_fault  # the same decision on every rank
+        flags = par.allreduce_host_scalars([1.0 if fault else 0.0, 1.0 if error else 0.0], dist.ReduceOp.MAX, self.device, self.group)
+        return total, flags[0] > 0.0, flags[1] > 0.0  # the same decisions on every rank
+
+    # ----- checkpoints: the reference's whole-module pickle (nerf.py:491) + what a bit-exact resume needs beside it -----
+    def _save_checkpoint(self, it: int, rays, mode: str, epoch_gen_state, next_batch: int):
+        os.makedirs(self.ckpt_path, exist_ok=True)
+        stem = self.ckpt_path + self.start_time + "_" + str(it)
+        # the module is pickled with the CONFIGURED batch size: a data-parallel rank's model is built for its slice (e.g. 512 of 4096), but
+        # the checkpoint must load anywhere and equal a single-process checkpoint of the same config (nerf.py:491, reloaded at :415)
+        prev = self.model.batch_ray
+        self.model.batch_ray = self.batch_ray
+        try:
+            torch.save(self.model, stem + ".pkl")
+        finally:
+            self.model.batch_ray = prev
+        # "<time>_<iter>.opt": Adam's moments and step (flat, parameters() order) and the sampler's position -- the reference saves neither
+        # (a resumed reference run restarts Adam from zero moments and its DataLoader from a fresh shuffle); absent file = that behaviour
+        torch.save({"format": 1, "iter": it, "mode": mode, "adam": self.optimizer.flat_state(),
+                    "sampler": {"epoch_gen_state": epoch_gen_state.cpu(), "next_batch": int(next_batch)}}, stem + ".opt")
+
+    def _load_opt_state(self, ckpt: str):
+        path = ckpt[:-4] + ".opt"
+        if not os.path.exists(path):
+            return None
+        st = torch.load(path, weights_only=False, map_location="cpu")
+        self.optimizer.load_flat_state(st["adam"])
+        return st
 
     # nerf.py:445-499
     def trainer(self, mode="train"):
@@ -244,9 +292,20 @@ class NeRFRunner:
         it = self.last_iter + 1
         t0, n0 = time.perf_counter(), it
         self.model.train()
+        skip = 0
+        if self._resume_sampler is not None and self._resume_sampler[0] == mode:
+            # continue the interrupted epoch: the generator state its permutation was drawn from, and the batches already used
+            rays.gen.set_state(self._resume_sampler[1]["epoch_gen_state"].cpu())
+            skip = int(self._resume_sampler[1]["next_batch"])
+        self._resume_sampler = None
         while it < self.total_iter:
-            batches = rays.epoch_sharded(self.batch_ray, self.rank, self.world) if self.distributed else rays.epoch(self.batch_ray)
+            epoch_gen_state = rays.gen.get_state()  # (a host copy of the generator's 16 bytes of Philox state: no device sync)
+            batches = (rays.epoch_sharded(self.batch_ray, self.rank, self.world, first_batch=skip) if self.distributed
+                       else rays.epoch(self.batch_ray, first_batch=skip))
+            bi = skip - 1
+            skip = 0
             for batch in batches:
+                bi += 1
                 row, col, pix_val, poses_bound, pic = batch[:5]
                 # (no zero_grad: the backward kernels OVERWRITE the bucket's views, which ARE p.grad; FusedAdam.step releases the bucket)
                 if self.distributed:
@@ -266,8 +325,14 @@ class NeRFRunner:
                     # the reference checks its resampling indices in EVERY forward and exit(0)s when a ray's coarse weights have all
                     # vanished (nerf.py:251-253) -- the state a run that has died stays in.  The kernels keep the bit in a sticky word
                     # across iterations; it is looked at here, where the loop syncs anyway, so nothing between two logs is missed
-                    fault = self.on_resample_fault != "ignore" and self.model.resample_fault_since(clear=True)
-                    lv, fault = self._global_loss_and_fault(loss, fault)
+                    err = None
+                    try:
+                        fault = self.on_resample_fault != "ignore" and self.model.resample_fault_since(clear=True)
+                    except _abi.NerfHipError as e:  # rank-local (e.g. STATUS_PREP_TIMEOUT): raised on EVERY rank behind the collectives below
+                        err, fault = e, False
+                    lv, fault, any_err = self._global_loss_and_fault(loss, fault, err is not None)
+                    if any_err:
+                        raise err if err is not None else _abi.NerfHipError(f"iteration <= {it}: another rank reported a library error at this logging point")
                     dt = time.perf_counter() - t0
                     self.writer.add_scalar("loss/" + mode, lv, it)
                     self.writer.add_scalar("lr/" + mode, self.optimizer.param_groups[0]["lr"], it)
@@ -288,8 +353,7 @@ class NeRFRunner:
                             raise ResampleIndexError(f"iteration <= {it}: resample index outside [0, Nf-1] (the reference exit(0)s here, nerf.py:251-253); "
                                                      "NeRFRunner(on_resample_fault='warn') trains on")
                 if (it + 1) % self.step == 0 and self.rank == 0:
-                    os.makedirs(self.ckpt_path, exist_ok=True)
-                    torch.save(self.model, self.ckpt_path + self.start_time + "_" + str(it) + ".pkl")
+                    self._save_checkpoint(it, rays, mode, epoch_gen_state, bi + 1)
                 it += 1
                 if it >= self.total_iter:
                     break

@@ -78,6 +78,44 @@ def test_runner_trains_checkpoints_and_renders(pkg, dev, tmp_path):
         assert torch.equal(p, q)
     assert abs(run2.optimizer.param_groups[0]["lr"] - 3e-3 * 0.1 ** (40 / 10000)) < 1e-9
     assert run2.trainer("train") == 44
+    # the checkpoint holds the CONFIGURED batch size and sits beside its optimizer / sampler state
+    assert torch.load(cks[-1], weights_only=False, map_location="cpu").batch_ray == 512
+    assert sorted(os.path.basename(f)[:-4] for f in glob.glob(ck + "*.opt"))[:2] == sorted(os.path.basename(f)[:-4] for f in cks)
+
+
+def test_resume_is_bit_exact(pkg, dev, tmp_path):
+    """VERDICT round 4, item 7 ("resume incl. optimizer state"): beside the reference-format `<time>_<iter>.pkl` (nerf.py:491) the
+    runner writes `<time>_<iter>.opt` -- Adam's moments and step, the sampler's generator state and position in the epoch -- and
+    NeRFRunner(continue_=True) (nerf.py:404-427) restores it: 40 iterations == 20 + resume + 20, bit for bit in fp32 (the checkpoint falls
+    into the middle of an epoch: 8 batches per epoch).  Without the `.opt` file a resume behaves like the reference's: zero moments."""
+    scene = pkg.data.synthetic_scene(n_pic=4, H=32, W=32, seed=1)
+    kw = dict(gpu=0, img_dir="", results_path=str(tmp_path) + "/res/", low_res=1, batch_ray=512, learning=3e-3, lr_gamma=0.1,
+              lr_milestone=[10, 200], n_coarse=32, n_fine=64, data_type="sync", step=20, decay_end=10000, sched="EXP",
+              datasets={"train": scene, "val": scene, "test": scene}, log_every=10)
+    torch.manual_seed(0)
+    a = pkg.NeRFRunner(continue_=False, ckpt_path=str(tmp_path) + "/a/", total_iter=40, **kw)
+    w0 = [p.detach().clone() for p in a.model.network.parameters()]
+    assert a.trainer("train") == 39
+    b1 = pkg.NeRFRunner(continue_=False, ckpt_path=str(tmp_path) + "/b/", total_iter=20, **kw)
+    with torch.no_grad():
+        for p, q in zip(b1.model.network.parameters(), w0):
+            p.copy_(q)  # the same initial weights as run a
+    assert b1.trainer("train") == 19
+    assert len(glob.glob(str(tmp_path) + "/b/*_19.opt")) == 1
+    b2 = pkg.NeRFRunner(continue_=True, ckpt_path=str(tmp_path) + "/b/", total_iter=40, **kw)
+    assert b2.last_iter == 19 and b2.optimizer._step == 20
+    assert b2.trainer("train") == 39
+    for (k, p), q in zip(a.model.network.named_parameters(), b2.model.network.parameters()):
+        assert torch.equal(p, q), (k, float((p - q).abs().max()))
+    assert torch.equal(a.optimizer._m, b2.optimizer._m) and torch.equal(a.optimizer._v, b2.optimizer._v)
+    # without the .opt file: the reference's behaviour (moments restart from zero) -- a different trajectory, still a valid resume
+    for f in glob.glob(str(tmp_path) + "/b/*.opt"):
+        os.remove(f)
+    for f in glob.glob(str(tmp_path) + "/b/*_39.pkl"):
+        os.remove(f)
+    b3 = pkg.NeRFRunner(continue_=True, ckpt_path=str(tmp_path) + "/b/", total_iter=40, **kw)
+    assert b3.last_iter == 19 and b3.optimizer._step == 0 and float(b3.optimizer._m.abs().max()) == 0.0
+    assert b3.trainer("train") == 39
 
 
 def test_parity_on_trained_weights(oracle, pkg, dev):

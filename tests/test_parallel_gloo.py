@@ -96,6 +96,74 @@ def test_bucket_and_sharding_world2():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+class _FakeModel:
+    """Stands in for NeRFModel in train_step_local: no kernels, a rank-local resample fault on demand."""
+
+    def __init__(self, params, fault):
+        self.params, self.fault = params, fault
+        self.ray0_near_far, self.grad_bucket, self.check_resample = None, None, True
+        self.saw_check_during_step = None
+
+    def train_step(self, row, col, pb, K, Ct):
+        self.saw_check_during_step = self.check_resample  # a rank-local raise inside the step would strand the other ranks
+        b = self.grad_bucket
+        b.pending = True
+        for v in b.views:
+            v.fill_(1.0)
+        for p, v in zip(self.params, b.views):
+            p.grad = v
+        return torch.zeros(row.shape[0], 3), torch.zeros(row.shape[0], 3), torch.tensor(1.0)
+
+    def resample_fault(self):
+        return self.fault
+
+
+def _fault_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nerf_tiny_amd as P
+        from nerf_tiny_amd import parallel as par
+
+        real = P.NeRFModel(64, 128, 8)
+        params = list(real.network.parameters())
+        b = par.GradBucket(params)
+        m = _FakeModel(params, fault=(rank == 1))  # ONLY rank 1 meets the reference's exit(0) condition
+        row = torch.zeros(4, dtype=torch.int64)
+        raised = False
+        try:
+            par.train_step_local(m, b, row, row, torch.zeros(4, 17), torch.eye(3), torch.zeros(4, 3), (2.0, 6.0), world)
+        except P.nerf.ResampleIndexError:
+            raised = True
+        # both ranks went through the gradient all-reduce (every view = 1 + 1) and BOTH raised; the check was off during the step itself
+        summed = all(bool((v == float(world)).all()) for v in b.views)
+        dist.barrier()  # nobody is stranded in a collective
+        q.put((rank, raised and summed and m.saw_check_during_step is False and m.check_resample is True and not b.pending))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rank_local_resample_fault_raises_on_every_rank_world2():
+    """a rank-local raise in front of a collective leaves the other ranks blocked until the RCCL timeout.  With
+    model.check_resample on, train_step_local makes the check BEHIND the gradient all-reduce, MAX-reduces its outcome and raises on every rank."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 def test_shard_bounds_properties():
     from nerf_tiny_amd import parallel as par
 
