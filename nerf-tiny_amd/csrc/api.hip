@@ -642,6 +642,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
     const unsigned char* bs = at<unsigned char>(ws, L.bsave);
     const unsigned char* bg = at<unsigned char>(ws, L.bG);
     float* slabs = at<float>(ws, L.bslabs);
+    const float* const slab_limit = slabs + dw_bf16_slab_floats();  // checked by launch_dw_bf16_multi before it enqueues anything
     auto X = [&](int t) { return bs + (size_t)wb_tot * bs_cum(t) * BF_FRAG_BYTES; };
     auto Gt = [&](int t) { return bg + (size_t)wb_tot * bg_cum(t) * BF_FRAG_BYTES; };
     int ns = 0;
@@ -681,19 +682,18 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       };
       float* end = slabs;
       if (early_event) {
-        HIP_TRY(launch_dw_bf16_multi(pr, n_early, wb_tot, slabs, &end, st));
+        HIP_TRY(launch_dw_bf16_multi(pr, n_early, wb_tot, slabs, slab_limit, &end, st));
         early_reds();
         HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
         HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(early_event), st));
         rb.n = 0;
-        HIP_TRY(launch_dw_bf16_multi(pr + n_early, n - n_early, wb_tot, end, &end, st));
+        HIP_TRY(launch_dw_bf16_multi(pr + n_early, n - n_early, wb_tot, end, slab_limit, &end, st));
         late_reds();
       } else {
-        HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, &end, st));
+        HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, slab_limit, &end, st));
         early_reds();
         late_reds();
       }
-      if ((size_t)(end - at<float>(ws, L.bslabs)) > dw_bf16_slab_floats()) return fail(NERF_HIP_ERR_WORKSPACE, "bf16 slab space exceeded");
       HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
       FoldGradArgs fg;
       fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
@@ -734,8 +734,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       const int i_c = n;
       pr[n++] = DwBfProd{Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, nullptr, 0};
       float* end = slabs;
-      HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, &end, st));
-      if ((size_t)(end - at<float>(ws, L.bslabs)) > dw_bf16_slab_floats()) return fail(NERF_HIP_ERR_WORKSPACE, "bf16 slab space exceeded");
+      HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, slab_limit, &end, st));
       if (i_l4 >= 0) red(pr[i_l4].slabs, pr[i_l4].nslab, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
       red(pr[i_l0].slabs, pr[i_l0].nslab, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1]);
       red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR]);

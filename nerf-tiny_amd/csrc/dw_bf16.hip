@@ -355,7 +355,7 @@ hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned c
 // n (<= 12) products of ANY of the shapes above in ONE launch of (at most) DWB_WGS workgroups, dealt out in proportion to the bytes a
 // product reads per wave block (largest remainder, at least one each, never more than wave blocks).  Fills p[i].slabs / p[i].nslab
 // (carved from slab_base in order) and returns the end of the used slab space in *slab_end.
-hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, float** slab_end, hipStream_t st) {
+hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, const float* slab_limit, float** slab_end, hipStream_t st) {
   if (n < 1 || n > DwBfMulti::MAXP || wb_tot < 1) return hipErrorInvalidValue;
   DwBfMulti m;
   memset(&m, 0, sizeof(m));
@@ -425,6 +425,7 @@ hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base
   }
   m.wg0[n] = wg0;
   if (slab_end) *slab_end = slab;
+  if (slab_limit && slab > slab_limit) return hipErrorOutOfMemory;  // the slabs of this plan would run past the workspace's slab space: nothing is enqueued
   static std::atomic<unsigned long long> opted{0};
   constexpr int lds_bytes = 144 * 1024;
   static_assert(DwbGeom<10, false>::LDS_BYTES <= lds_bytes && DwbGeom<9, true>::LDS_BYTES <= lds_bytes && DwbGeom<8, false>::LDS_BYTES <= lds_bytes &&

@@ -311,7 +311,8 @@ struct DwBfProd {
   const unsigned char* Z;
   float* slabs; int nslab;
 };
-hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, float** slab_end, hipStream_t st);
+// slab_limit: one past the slab space (checked on the host BEFORE the launch: hipErrorOutOfMemory, nothing enqueued) or null
+hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, const float* slab_limit, float** slab_end, hipStream_t st);
 hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count,
                                  float* dW, int ldw, int col0, float* db, hipStream_t st);
 // dW[o][col0 + i - i_first] = sum over slabs of row o_first + o, column i; db[o] likewise from the last slab column
