@@ -356,15 +356,16 @@ class NeRFModel(nn.Module):
         """Did ANY forward on the current workspaces meet that condition since the last call that cleared the record?  The kernels OR the
         status bits into a sticky word no forward resets (``nerf_hip_read_status_sticky``), so a train loop that looks only at its logging
         points misses nothing in between -- the reference checks every forward (nerf.py:251-253).  One host sync per workspace."""
-        hit = False
-        for _, ws in self._ws.values():
+        hit = timeout = False
+        for _, ws in self._ws.values():  # every workspace is read (and cleared) before anything is raised
             st = C.c_uint32(0)
             _abi.check(_abi.lib().nerf_hip_read_status_sticky(ws.data_ptr(), ws.numel(), C.byref(st), 1 if clear else 0,
                                                               torch.cuda.current_stream(ws.device).cuda_stream))
-            if st.value & _abi.STATUS_PREP_TIMEOUT:
-                raise _abi.NerfHipError("a bf16-MLP call's one-launch preparation gave up waiting for the weight fold (prep_bf16.hip): the results "
-                                        "of that call are wrong")
+            timeout = timeout or bool(st.value & _abi.STATUS_PREP_TIMEOUT)
             hit = hit or bool(st.value & _abi.STATUS_RESAMPLE_INDEX)
+        if timeout:
+            raise _abi.NerfHipError("a bf16-MLP call's one-launch preparation gave up waiting for the weight fold (prep_bf16.hip): the packed "
+                                    "weight image of that call was poisoned, its results are NaN")
         return hit
 
     @torch.no_grad()
