@@ -111,13 +111,26 @@ __device__ __forceinline__ void dw_bf16_body(const DwBfArgs& a, unsigned char* l
       pc = pc < total ? pc : total - 1;
       const unsigned char* src;
       int ks, dst;
+      // (timing experiments only, results wrong: NERF_TIMING_DW_HALF_G / _X read every second piece twice -> half the distinct bytes of
+      // that operand reach HBM, the instruction stream and the LDS image stay as they are: the upper bound of what a design that moves
+      // half the bytes -- alternate-layer recompute for X, zero-compaction for both -- could gain in this phase)
+#ifdef NERF_TIMING_DW_HALF_G
+#define DWB_GSRC(k) ((k) >> 1)
+#else
+#define DWB_GSRC(k) (k)
+#endif
+#ifdef NERF_TIMING_DW_HALF_X
+#define DWB_XSRC(k) ((k) >> 1)
+#else
+#define DWB_XSRC(k) (k)
+#endif
       if (pc < gks) {
         ks = pc; dst = ks;
-        src = gG + ((size_t)wb * gks + ks) * BF_FRAG_BYTES;
+        src = gG + ((size_t)wb * gks + DWB_GSRC(ks)) * BF_FRAG_BYTES;
       } else if (pc < gks + XKS) {
         const int x = pc - gks;
         ks = x; dst = 16 + x;  // parity of the slot piece = parity of x (x1_ks is even)
-        src = x < x1 ? gX1 + ((size_t)wb * x1 + x) * BF_FRAG_BYTES : a.X2 + ((size_t)wb * (XKS - x1) + (x - x1)) * BF_FRAG_BYTES;
+        src = x < x1 ? gX1 + ((size_t)wb * x1 + DWB_XSRC(x)) * BF_FRAG_BYTES : a.X2 + ((size_t)wb * (XKS - x1) + DWB_XSRC(x - x1)) * BF_FRAG_BYTES;
       } else {
         ks = pc - gks - XKS; dst = 16 + XKS + ks;
         src = a.Z + ((size_t)wb * 2 + ks) * BF_FRAG_BYTES;

@@ -138,6 +138,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_bwd_bf16(const FieldBwd
   // `lane16` = this lane's byte offset inside a piece; the epilogues pass one produced at THEIR program point (lane_id_here): an
   // address register kept from the prologue lives across the whole stream -- the allocator parked five of them in scratch
   auto grad_piece = [&](int tensor, int ks, const u32x4& v, unsigned lane16) {
+#ifdef NERF_TIMING_G_HALF  // (timing experiments only, results wrong: half the distinct gradient bytes reach HBM)
+    ks >>= 1;
+#endif
     store_piece(a.bG + ((size_t)a.wb_tot * bg_cum(tensor) + (size_t)wb * bg_ks(tensor) + ks) * BF_FRAG_BYTES + lane16, v);
   };
   grad_piece(BG_Z, 0, zin[0], lane * 16);

@@ -140,7 +140,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_fwd_bf16(const FieldArg
   unsigned mw[4];  // (every word is assigned by its even tile before the odd one ORs into it; words 2, 3 of a 4-tile layer are written as 0)
   // `lane16` = this lane's byte offset inside a piece.  The layers' epilogues pass a value produced AT their program point (mbcnt): left
   // alone the compiler forms every layer's 64-bit store address in the prologue and parks them -- and the lane pointer -- in scratch
+  // (timing experiments only, results wrong -- DESIGN.md section 9: NERF_TIMING_SAVE_HALF writes every second piece of a saved tensor over its
+  // neighbour, i.e. half the distinct bytes reach HBM -- what zero-compaction could at most take out of this kernel; NERF_TIMING_SAVE_SKIPALT
+  // sends h1, h3, h5, h7 to one aliased KiB per wave -- what alternate-layer recompute in the weight-gradient kernels would not write)
   auto save_piece = [&](int tensor, int ks, const u32x4& v, unsigned lane16) {
+#if defined(NERF_TIMING_SAVE_HALF)
+    ks >>= 1;
+#elif defined(NERF_TIMING_SAVE_SKIPALT)
+    if (tensor == BS_H0 + 1 || tensor == BS_H0 + 3 || tensor == BS_H0 + 5 || tensor == BS_H0 + 7) {
+      store_piece(a.bsave + (size_t)c.wv * BF_FRAG_BYTES + lane16, v);
+      return;
+    }
+#endif
     store_piece(a.bsave + ((size_t)a.wb_tot * bs_cum(tensor) + (size_t)wb * bs_ks(tensor) + ks) * BF_FRAG_BYTES + lane16, v);
   };
   if (SAVE) {
