@@ -216,7 +216,7 @@ PMC_SPLIT_FILE = "pmc_split_fwd_latest.json"
 
 
 def pmc_file(leg):
-    return PMC_SPLIT_FILE if getattr(leg, "split", False) and not leg.train else PMC_FILES[(leg.train, leg.bf16)]
+    return PMC_SPLIT_FILE if getattr(leg, "split", False) else PMC_FILES[(leg.train, leg.bf16)]
 
 
 def read_traffic(leg, kernel_keys, scale=None):
@@ -255,8 +255,7 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket, time_allred
 
     row, col, pb, C_true = inputs
     model.bf16_mlp = leg.bf16
-    model.split_mlp = leg.split and not leg.train
-    model.split_train = leg.split and leg.train  # opt-in: the training call's FORWARD on the split-fp32 kernel, backward exact fp32
+    model.split_mlp = leg.split
     model.grad_bucket = bucket if leg.train else None
     ar_events = []
 
@@ -321,7 +320,7 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket, time_allred
         elapsed = float(t.item())
     ar_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)) if ar_events else None
     model.grad_bucket = None
-    model.split_mlp = model.split_train = False
+    model.split_mlp = False
     return elapsed, prof, ar_ms
 
 
@@ -353,8 +352,8 @@ def rooflines(leg, prof, b_local, steps):
     # EXECUTE -- 8/9 of the reference network's 1,182,976 per sample: point_info is folded into dir_info (one 128 x 256
     # layer instead of 256 x 256 + 128 x 256) -- so `frac` is a hardware fraction (<= 1); the reference graph's
     # FLOPs over the same time are `achieved_algorithmic` / `frac_algorithmic`.
-    def split_block():
-        # split-fp32 forward: the fp32 MLP on the bf16 pipe, THREE bf16 MFMAs (hi*hi, hi*mid, mid*hi) per fp32 product.  Roofline = the
+    if getattr(leg, "split", False):
+        # split-fp32 inference: the fp32 MLP on the bf16 pipe, THREE bf16 MFMAs (hi*hi, hi*mid, mid*hi) per fp32 product.  Roofline = the
         # bf16 MFMA peak against the bf16 FLOPs the kernel executes (3 x the executed fp32 ones); the algorithmic fp32 figure beside it
         ms = sum(prof.get(k, (0.0, 0))[0] for k in ("field_fwd_coarse", "field_fwd_fine"))
         n = sum(prof.get(k, (0.0, 0))[1] for k in ("field_fwd_coarse", "field_fwd_fine"))
@@ -362,17 +361,15 @@ def rooflines(leg, prof, b_local, steps):
         alg = FLOP_PER_SAMPLE * b_local * (NC + NF) // 2
         exe = 3 * EXEC_FLOP_PER_SAMPLE * b_local * (NC + NF) // 2
         ach = exe / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
-        return {"bound": "mfma (bf16 pipe)", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
-                "traffic": None if leg.train else scaled(read_traffic(leg, ["k_field_fwd_split"])), "traffic_source": src,
-                "kernel": "k_field_fwd_split" + ("<SAVE>" if leg.train else "") + " (average of the coarse- and fine-pass launches)", "avg_launch_ms": round(avg, 4), "launches": n,
-                "flop_per_launch": exe, "achieved_algorithmic_fp32": round(alg / (avg * 1e-3) / 1e12, 2) if avg > 0 else 0.0,
-                "algorithmic_over_fp32_mfma_peak": round(alg / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3) if avg > 0 else 0.0,
-                "note": "achieved = executed bf16 MFMA FLOPs (3 per fp32 product of the folded network) against the dense bf16 peak; "
-                        "achieved_algorithmic_fp32 = the reference network's fp32 FLOPs (SURVEY.md 8d) per second, above the fp32 MFMA peak because "
-                        "the products run on the bf16 pipe with 16-bit-mantissa operands (parity: `parity.split_mlp_vs_reference`)"}
-
-    if getattr(leg, "split", False) and not leg.train:
-        return split_block(), None
+        blk = {"bound": "mfma (bf16 pipe)", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+               "traffic": scaled(read_traffic(leg, ["k_field_fwd_split"])), "traffic_source": src,
+               "kernel": "k_field_fwd_split (average of the coarse- and fine-pass launches)", "avg_launch_ms": round(avg, 4), "launches": n,
+               "flop_per_launch": exe, "achieved_algorithmic_fp32": round(alg / (avg * 1e-3) / 1e12, 2) if avg > 0 else 0.0,
+               "algorithmic_over_fp32_mfma_peak": round(alg / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3) if avg > 0 else 0.0,
+               "note": "achieved = executed bf16 MFMA FLOPs (3 per fp32 product of the folded network) against the dense bf16 peak; "
+                       "achieved_algorithmic_fp32 = the reference network's fp32 FLOPs (SURVEY.md 8d) per second, above the fp32 MFMA peak because "
+                       "the products run on the bf16 pipe with 16-bit-mantissa operands (parity: `parity.split_mlp_vs_reference`)"}
+        return blk, None
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
     fwd_key = (["k_field_fwd_bf16<true, 8>"] if leg.train else ["k_field_fwd_bf16x<2, 8>"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
     if "render_pair" in prof:  # small bf16-MLP inference batches: ONE launch holds both field passes and both composites of every ray pair
@@ -382,9 +379,7 @@ def rooflines(leg, prof, b_local, steps):
     else:
         fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
                    FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)
-    if getattr(leg, "split", False) and leg.train:  # the opt-in split-forward train step: forward phase = the split kernel with saves
-        fwd = split_block()
-    fwd["note"] = fwd.get("note") or ("achieved / frac count the FLOPs the kernel EXECUTES (8/9 of the reference network's: point_info folded into dir_info, "
+    fwd["note"] = ("achieved / frac count the FLOPs the kernel EXECUTES (8/9 of the reference network's: point_info folded into dir_info, "
                    "DESIGN.md 3a) -- the MFMA pipe's side, the figure the MFMA-busy counter corroborates; achieved_algorithmic / frac_algorithmic "
                    "price the reference graph's FLOPs (SURVEY.md 8d) over the same time")
     if not leg.train:
@@ -486,10 +481,9 @@ def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong)
     roof, phases = rooflines(leg, prof, b_local, steps)
     rep = {"metric": "rays/sec (64 coarse + 128 fine samples), lego 400x400" + (" [train step: fwd+loss+bwd]" if leg.train else "")
                      + (" [cfg3: bf16 MLP / fp32 composite]" if leg.bf16 else "")
-                     + (" [split-fp32 inference: fp32 operands as bf16 hi + mid, 3 bf16 MFMAs per product, fp32 accumulate; same 1e-4 bar]" if getattr(leg, "split", False) and not leg.train else "")
-                     + (" [opt-in: FORWARD on the split-fp32 kernel (bf16 hi + mid operands, fp32 accumulate), backward exact fp32]" if getattr(leg, "split", False) and leg.train else ""),
+                     + (" [split-fp32 inference: fp32 operands as bf16 hi + mid, 3 bf16 MFMAs per product, fp32 accumulate; same 1e-4 bar]" if getattr(leg, "split", False) else ""),
            "value": round(value, 1), "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
-           "dtype": "bf16" if leg.bf16 else (("f32 (forward: bf16 hi+mid split operands, fp32 accumulate; backward: exact f32)" if leg.train else "f32 (bf16 hi+mid split operands, fp32 accumulate)") if getattr(leg, "split", False) else "f32"), "roofline": roof,
+           "dtype": "bf16" if leg.bf16 else ("f32 (bf16 hi+mid split operands, fp32 accumulate)" if getattr(leg, "split", False) else "f32"), "roofline": roof,
            "whole_path_tflops_per_gpu": round(value / world * flop_ray / 1e12, 2),
            "whole_path_frac_of_mfma_peak": round(value / world * flop_ray / 1e12 / (PEAK_BF16_MFMA_TFLOPS if leg.bf16 else PEAK_F32_MFMA_TFLOPS), 4),  # (split leg: of the FP32 peak, i.e. > 1)
            "whole_path_note": "whole_path_* price the ALGORITHMIC FLOPs of the reference graph (SURVEY.md 8d) over the whole step; x 8/9 for the executed side",
@@ -611,7 +605,7 @@ def compact_line(full, side_path=None):
     if "allreduce_ms" in full:
         line["allreduce_ms"] = full["allreduce_ms"]
     ex = full.get("extra", {})
-    for name in ("train_f32", "forward_bf16", "train_bf16", "forward_f32_split", "train_f32_split"):
+    for name in ("train_f32", "forward_bf16", "train_bf16", "forward_f32_split"):
         if name in ex:
             line[name + "_rays_per_s"] = ex[name].get("value")
     for name in ("train_f32", "train_bf16"):  # the N > 1 strong-scaling legs: one 4096-ray batch split over the ranks
@@ -777,7 +771,7 @@ def main():
     extra = {}
     # (name, train, bf16, timed steps, warm-up steps): every leg is timed over >= 0.1 s
     legs = (("forward_f32", False, False, 20, 3), ("train_f32", True, False, 8, 2), ("forward_bf16", False, True, 160, 8), ("train_bf16", True, True, 40, 4),
-            ("forward_f32_split", False, False, 60, 4), ("train_f32_split", True, False, 8, 2))
+            ("forward_f32_split", False, False, 60, 4))
     def brief(r, rays_per_step):
         return {k: r[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_with_kernel_events", "steps", "dtype", "kernel_ms_per_step", "allreduce_ms") if k in r} | {
             "rays_per_step": rays_per_step, "roofline_frac": r["roofline"]["frac"], "roofline_frac_algorithmic": r["roofline"].get("frac_algorithmic"),
