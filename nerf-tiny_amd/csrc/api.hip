@@ -343,8 +343,7 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   const bool bf16x = bf16 && !save && !(flags & NERF_HIP_FORCE_TILE_KERNEL);
   // split-fp32 inference (field_fwd_split.hip): fp32 operands as two bf16 parts, three bf16 MFMAs per product
   const bool split = (flags & NERF_HIP_SPLIT_MLP) && !bf16;
-  // (split && save: the opt-in split-fp32 TRAINING forward -- the split kernel leaves the fp32 rows / masks / spre of k_field_fwd_reg<SAVE>, the
-  // backward runs the exact-fp32 chain and weight-gradient kernels on them)
+  if (split && save) return fail(NERF_HIP_ERR_ARG, "NERF_HIP_SPLIT_MLP is an inference mode: not with NERF_HIP_SAVE_FOR_BACKWARD");
   const Weights24 w = as_w24(weights24);
 
   ProfChain pc;  // the phases below follow each other with nothing in between
@@ -357,10 +356,8 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED) && !one_prep) {
     ProfScope ps(NERF_HIP_K_PACK, st, &pc);
     if (bf16 || split) HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));  // fp32 W_fold, b_fold for the bf16 / split packers (bf16_common.h)
-    if (split) {
-      HIP_TRY(launch_pack_weights_split(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_sp), st));
-      if (save) HIP_TRY(launch_pack_weights(w, at<float>(ws, L.fold), at<float4>(ws, L.packed), NSEG, st));  // the fp32 image of the backward chain
-    } else
+    if (split) HIP_TRY(launch_pack_weights_split(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_sp), st));
+    else
     if (bf16 && bf16x) HIP_TRY(launch_pack_weights_bf16x(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
     else if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
     else HIP_TRY(launch_pack_weights(w, at<float>(ws, L.fold), at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
@@ -443,7 +440,7 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   FwdFuse ff;
   memset(&ff, 0, sizeof(ff));
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  auto field = [&](const FieldArgs& f) { return split ? launch_field_fwd_split(f, save, st) : bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st, ff.mode ? &ff : nullptr) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
+  auto field = [&](const FieldArgs& f) { return split ? launch_field_fwd_split(f, st) : bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st, ff.mode ? &ff : nullptr) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
 
   CoarseArgs ca;
   memset(&ca, 0, sizeof(ca));

@@ -8,12 +8,8 @@
 // fp32 biases, fp32 everything else.  Measured against the reference's own outputs this evaluation sits where the exact-fp32 kernels
 // sit (C_coarse 3e-6, C_fine 2e-5 max-rel on the golden cfg2 case: tests/test_gpu_split.py; the emulation of exactly this
 // arithmetic in the build container: 3.3e-6 / 2.2e-5) -- the 1e-4 bar is met with the same margin, because what limits both is the
-// conditioning of the fine pass, not the sixteenth bit of a product.  It is an OPT-IN mode (NERF_HIP_SPLIT_MLP, model.split_mlp): the
-// default path keeps the exact k-ordered fp32 fma chains.
-// SAVE (NERF_HIP_SPLIT_MLP | NERF_HIP_SAVE_FOR_BACKWARD, model.split_train; opt-in, never the headline): the same kernel also leaves what the
-// exact-fp32 backward needs -- the fp32 rows of gamma_p, h0..h7 and c, the u16 ReLU masks of h0..h7 in the tile kernels' layout, the sigma
-// pre-activation -- exactly where k_field_fwd_reg<SAVE> leaves them, so that the dX chain and the weight-gradient products (exact fp32
-// kernels) run unchanged on a forward that took a third of the time.
+// conditioning of the fine pass, not the sixteenth bit of a product.  It is an OPT-IN inference mode (NERF_HIP_SPLIT_MLP,
+// model.split_mlp): the default path keeps the exact k-ordered fp32 fma chains, and training always uses them.
 //
 // Machinery: bf16_stream.h (LDS ring of 1-KiB A fragments filled by direct-to-LDS loads, activations in registers, the accumulator
 // of one layer = the operand of the next), in a 4-wave form: ONE wave per SIMD (the two-part activations of a layer's input and
@@ -29,48 +25,12 @@ constexpr int SP_NCHUNK = SP_NFRAG / BF_CHUNK;
 static_assert(SP_NCHUNK * BF_CHUNK == SP_NFRAG, "whole chunks");
 constexpr int SP_WG = 256;                        // 4 waves x 32 samples
 
-// ---- store schedule of the SAVE variant (bf16_stream.h: stores share the vmcnt queue with the ring's loads and retire in order, so every
-// counted wait must allow for the younger ones).  Counted are the stores EVERY lane of the wave issues unconditionally: per finished
-// tile four 16-byte row stores (parts 1, 3, 5, 7 of its epilogue) and, for the trunk layers, one mask word (part 7).  A spread epilogue
-// (segments of >= BF_EPI_POS + 8 k-steps) issues part p in step BF_EPI_POS + p of the next tile, a lumped one everything in step
-// BF_EPI_POS.  The conditional stores (sigma, spre: lane half 0 of valid samples) are NOT counted -- an uncounted store only makes a wait
-// more conservative, a counted one that is not issued would make it too short.
-struct SplitSeg { int s0, nft, ks; int prev_rows, prev_mask, own_rows, own_mask; };  // s0 in STEPS (= bf16 fragment index); epilogues: the previous segment's last tile / own tiles
-constexpr SplitSeg kSplitSegs[] = {
-    {BFS_L0, 8, 4, 0, 0, 4, 1},        {BFS_L1, 8, 16, 4, 1, 4, 1},       {BFS_L1 + 128, 8, 16, 4, 1, 4, 1}, {BFS_L1 + 256, 8, 16, 4, 1, 4, 1},
-    {BFS_L4, 8, 20, 4, 1, 4, 1},       {BFS_L5, 8, 16, 4, 1, 4, 1},       {BFS_L5 + 128, 8, 16, 4, 1, 4, 1}, {BFS_L5 + 256, 8, 16, 4, 1, 4, 1},
-    {BFS_SIG, 1, 16, 4, 1, 0, 0},      {BFS_DIR, 4, 18, 0, 0, 4, 0},      {BFS_COL, 1, 8, 4, 0, 0, 0}};
-struct SplitStoreTable { int cum[SP_NFRAG + 1]; };
-constexpr SplitStoreTable make_split_store_table() {
-  SplitStoreTable t{};
-  int ev[BF_NFRAG + 64] = {};  // counted stores issued in step i (after that step's sync point)
-  for (const SplitSeg& g : kSplitSegs)
-    for (int f = 0; f < g.nft; ++f) {
-      const int rows = f == 0 ? g.prev_rows : g.own_rows, mask = f == 0 ? g.prev_mask : g.own_mask;
-      const int step0 = g.s0 + f * g.ks + BF_EPI_POS;
-      if (g.ks >= BF_EPI_POS + 8) {
-        for (int part = 0; part < 8; ++part) ev[step0 + part] += ((part & 1) ? rows / 4 : 0) + (part == 7 ? mask : 0);
-      } else {
-        ev[step0] += rows + mask;
-      }
-    }
-  int run = 0, step = 0;
-  for (int i = 0; i <= SP_NFRAG; ++i) {  // fragment index i: the steps before it are 0 .. i / 2 - 1 (sync points sit on even indices)
-    while (step < i / 2) run += ev[step++];
-    t.cum[i] = run;
-  }
-  return t;
-}
-constexpr SplitStoreTable kSplitStoreTable = make_split_store_table();
-
-template <bool SAVE>
-struct SplitStreamT {
+struct SplitStream {
   static constexpr int NFRAG = SP_NFRAG, NCHUNK = SP_NCHUNK, NS = BF_NS, RING_OFF = BF_BIAS_BYTES, D = 6, PW = 4;
   static constexpr bool HAS_BIAS = true;
-  static constexpr int PROLOGUE_STORES = SAVE ? 8 : 0;  // gamma_p: two 16-byte row stores per k-step
-  __device__ static constexpr int stores_before(int idx) { return SAVE ? kSplitStoreTable.cum[idx] : 0; }
+  static constexpr int PROLOGUE_STORES = 0;
+  __device__ static constexpr int stores_before(int) { return 0; }
 };
-using SplitStream = SplitStreamT<false>;
 static_assert(BF_SYNC_POS % 2 == 0 && SplitStream::D % 2 == 0, "a step's two fragments stay in one chunk / keep their ring parity");
 
 // two fp32 values -> their hi parts (packed bf16 pair) and mid parts
@@ -89,8 +49,7 @@ __device__ __forceinline__ HiMid split2(float x0, float x1) {
 // 8 register pairs of a tile (epi(f, part, acc): ~13 vector instructions each) go one per k-step behind k-steps 2 .. 9 of the next
 // tile -- about four vector instructions per MFMA, which the 32-cycle MFMA hides -- instead of ~110 in one lump.  Segments shorter than
 // ten k-steps keep the lump.
-struct EpiTmp { float x0, x1; unsigned hi; float r0, r1; unsigned mbits; };  // state of one register pair between the three phases of its conversion
-                                                                              // (SAVE: + the previous pair's values for a 16-byte store, the tile's mask bits)
+struct EpiTmp { float x0, x1; unsigned hi; };  // state of one register pair between the three phases of its conversion
 
 template <class S, int S0, int NFT, int KSA, int KSB, int BT0, int P0, int NEXT_BT, class Epi, class PrevEpi>
 __device__ __forceinline__ void sp_segment(const BfCtx& c, u32x4 (&fr)[S::D], f32x16 (&acc)[2], const u32x4* inA_hi, const u32x4* inA_mid,
@@ -100,7 +59,7 @@ __device__ __forceinline__ void sp_segment(const BfCtx& c, u32x4 (&fr)[S::D], f3
   constexpr int LAST = SPREAD ? BF_EPI_POS + 7 : BF_EPI_POS;  // k-step behind which the finished accumulator is free again
   static_assert(KS > LAST, "segment too short for the deferred epilogue");
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  EpiTmp tmp = {0.f, 0.f, 0u, 0.f, 0.f, 0u};
+  EpiTmp tmp = {0.f, 0.f, 0u};
   static_for<NFT * KS>([&](auto I) {
     constexpr int f = I / KS, ks = I % KS, i0 = 2 * (S0 + I), i1 = i0 + 1;
     constexpr int cur = (P0 + f) & 1, oth = (P0 + f + 1) & 1;
@@ -156,10 +115,9 @@ __device__ __forceinline__ void sp_segment(const BfCtx& c, u32x4 (&fr)[S::D], f3
   });
 }
 
-template <bool SAVE>
 __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  using S = SplitStreamT<SAVE>;
+  using S = SplitStream;
   BfCtx c;
   c.wimg = a.wbf;
   c.lds = lds;
@@ -181,28 +139,13 @@ __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a)
 #pragma unroll
   for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p[i]), "+v"(dw[i]));
 
-  // ---- training: this lane's row of the fp32 save tensors and its mask words (the layout k_field_fwd_reg<SAVE> writes: kernels.h FieldArgs);
-  // lanes past the end of the pass own a dump row, so no store carries a predicate
-  const size_t MS = (size_t)a.MSrows * WIDTH;
-  const long long rrow = valid ? (long long)(a.row0 + m) : a.Mtot + j;
-  float* const srow = SAVE ? a.save + (size_t)rrow * WIDTH + 4 * h : nullptr;
-  const int m0 = blockIdx.x * (SP_WG / 2) + c.wv * 32;  // first sample of this wave
-  // (a wave wholly past the end of the pass -- the last workgroup of a pass whose size is not a multiple of 128 -- still issues every store
-  // the counted waits expect: its rows are dump rows, its mask words go to the same dump area, all layers to one place)
-  const bool wave_live = m0 < a.M;
-  uint16_t* const mrow = !SAVE ? nullptr
-                         : wave_live ? a.masks + ((size_t)(a.tile0 + (m0 >> 6)) * 4 + ((m0 >> 5) & 1)) * 256 + h * 32 + j
-                                     : reinterpret_cast<uint16_t*>(a.save + (size_t)a.Mtot * WIDTH) + h * 32 + j;
-  const size_t MKS = wave_live ? (size_t)a.tiles_tot * 4 * 256 : 0;
-
   bf_stream_start<S>(c);
 
   // ---- positional encodings (fp32, as in the exact path) straight into two-part B operands:
   // k-step ks, slot pair (s, s+1): features k = 16ks + 4h + {0,1 | 2,3 | 8,9 | 10,11} = (sin, cos) pairs pi = 8ks + 2h + {0, 1, 4, 5}
   u32x4 gp_hi[4], gp_mid[4], gd_hi[2], gd_mid[2];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    float g8[8];  // SAVE: this lane's eight fp32 encodings of k-step ks: features 16ks + 4h + {0..3} and 16ks + 8 + 4h + {0..3}
+  for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int pi = 8 * ks + 2 * h + (q & 1) + 4 * (q >> 1);
@@ -219,14 +162,7 @@ __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a)
       const HiMid e = split2(sv, cv);
       gp_hi[ks][q] = e.hi;
       gp_mid[ks][q] = e.mid;
-      g8[2 * q] = sv;
-      g8[2 * q + 1] = cv;
     }
-    if (SAVE) {  // row-major gamma_p (tensor S_GP, 64 columns used): column = feature index, as k_field_fwd_reg<SAVE> stores it
-      store_row4(srow + S_GP * MS + 16 * ks, make_float4(g8[0], g8[1], g8[2], g8[3]));
-      store_row4(srow + S_GP * MS + 16 * ks + 8, make_float4(g8[4], g8[5], g8[6], g8[7]));
-    }
-  }
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -255,31 +191,14 @@ __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a)
   acc[0] = bf_bias_tile(c, BFB_L0);
   // epilogue of a ReLU layer, one register pair group at a time: part = (mh, q) of tile f (fp32 accumulators) -> ReLU (one integer max
   // per value: the fp32 bit pattern of max(x, 0)) -> two-part packed slot q of k-step 2f + mh of the next layer's input
-  // SAVE: `tensor` >= 0 -> the activated values also go to the fp32 rows of that save tensor (lane (j, h) owns the 16-byte groups
-  // 32f + 8g + 4h of row j: registers 4g .. 4g + 3 = two consecutive parts), `mlayer` >= 0 -> and the tile's u16 ReLU mask word (bit r =
-  // register r > 0) to the mask buffer in the tile kernels' layout (entry (f & 1, f >> 1): field_fwd_reg.hip)
-  auto relu_to = [&](u32x4* oh, u32x4* om, int tensor, int mlayer) {
-    return [oh, om, tensor, mlayer, srow, mrow, MS, MKS](int f, int part, int ph, const f32x16& A, EpiTmp& t) {
+  auto relu_to = [&](u32x4* oh, u32x4* om) {
+    return [oh, om](int f, int part, int ph, const f32x16& A, EpiTmp& t) {
       const int mh = part >> 2, q = part & 3;
       if (ph == 0) {  // ReLU (integer max on the fp32 bit patterns), hi parts
         t.x0 = __int_as_float(max(__float_as_int(A[8 * mh + 2 * q]), 0));
         t.x1 = __int_as_float(max(__float_as_int(A[8 * mh + 2 * q + 1]), 0));
         t.hi = pack2(t.x0, t.x1);
         oh[2 * f + mh][q] = t.hi;
-        if (SAVE && tensor >= 0) {
-          if ((q & 1) == 0) {
-            t.r0 = t.x0;
-            t.r1 = t.x1;
-          } else {
-            store_row4(srow + (size_t)tensor * MS + 32 * f + 8 * (2 * mh + (q >> 1)), make_float4(t.r0, t.r1, t.x0, t.x1));
-          }
-          if (mlayer >= 0) {  // a ReLU'd value is >= +0: alive <=> its bit pattern is >= 1
-            const unsigned b0 = (unsigned)min(__float_as_int(t.x0), 1), b1 = (unsigned)min(__float_as_int(t.x1), 1);
-            const unsigned both = (b0 << (8 * mh + 2 * q)) | (b1 << (8 * mh + 2 * q + 1));
-            t.mbits = part == 0 ? both : (t.mbits | both);
-            if (part == 7) mrow[(size_t)mlayer * MKS + ((f & 1) * 2) * 256 + (f >> 1) * 64] = (uint16_t)t.mbits;
-          }
-        }
       } else if (ph == 1) {  // residuals
         t.x0 -= __uint_as_float(t.hi << 16);
         t.x1 -= __uint_as_float(t.hi & 0xffff0000u);
@@ -292,28 +211,24 @@ __global__ __launch_bounds__(SP_WG, 1) void k_field_fwd_split(const FieldArgs a)
   auto nothing = [](int, int, const f32x16&, EpiTmp&) {};
   auto nothing_f = [](int, int, int, const f32x16&, EpiTmp&) {};
 
-  // ---- layers 0..7 (nerf.py:104-112); e_l = the epilogue that turns layer l's accumulators into h_l (and, SAVE, stores it + its masks)
-  auto e0 = relu_to(Xh, Xm, S_H0 + 0, 0), e1 = relu_to(Yh, Ym, S_H0 + 1, 1), e2 = relu_to(Xh, Xm, S_H0 + 2, 2), e3 = relu_to(Yh, Ym, S_H0 + 3, 3);
-  auto e4 = relu_to(Xh, Xm, S_H0 + 4, 4), e5 = relu_to(Yh, Ym, S_H0 + 5, 5), e6 = relu_to(Xh, Xm, S_H0 + 6, 6), e7 = relu_to(Yh, Ym, S_H0 + 7, 7);
-  auto ec = relu_to(Xh, Xm, S_C, -1);  // c = relu(dir_info pre-activation): 128 columns, its mask is re-derived from the saved values
-  sp_segment<S, BFS_L0, 8, 4, 0, BFB_L0, 0, BFB_L0 + 8>(c, fr, acc, gp_hi, gp_mid, nullptr, nullptr, e0, nothing);
-  sp_segment<S, BFS_L1, 8, 16, 0, BFB_L0 + 8, 0, BFB_L0 + 16>(c, fr, acc, Xh, Xm, nullptr, nullptr, e1, last_of(e0, 7));
-  sp_segment<S, BFS_L1 + 128, 8, 16, 0, BFB_L0 + 16, 0, BFB_L0 + 24>(c, fr, acc, Yh, Ym, nullptr, nullptr, e2, last_of(e1, 7));
-  sp_segment<S, BFS_L1 + 256, 8, 16, 0, BFB_L0 + 24, 0, BFB_L0 + 32>(c, fr, acc, Xh, Xm, nullptr, nullptr, e3, last_of(e2, 7));
-  sp_segment<S, BFS_L4, 8, 16, 4, BFB_L0 + 32, 0, BFB_L0 + 40>(c, fr, acc, Yh, Ym, gp_hi, gp_mid, e4, last_of(e3, 7));
-  sp_segment<S, BFS_L5, 8, 16, 0, BFB_L0 + 40, 0, BFB_L0 + 48>(c, fr, acc, Xh, Xm, nullptr, nullptr, e5, last_of(e4, 7));
-  sp_segment<S, BFS_L5 + 128, 8, 16, 0, BFB_L0 + 48, 0, BFB_L0 + 56>(c, fr, acc, Yh, Ym, nullptr, nullptr, e6, last_of(e5, 7));
-  sp_segment<S, BFS_L5 + 256, 8, 16, 0, BFB_L0 + 56, 0, BFB_SIGMA>(c, fr, acc, Xh, Xm, nullptr, nullptr, e7, last_of(e6, 7));
+  // ---- layers 0..7 (nerf.py:104-112)
+  sp_segment<S, BFS_L0, 8, 4, 0, BFB_L0, 0, BFB_L0 + 8>(c, fr, acc, gp_hi, gp_mid, nullptr, nullptr, relu_to(Xh, Xm), nothing);
+  sp_segment<S, BFS_L1, 8, 16, 0, BFB_L0 + 8, 0, BFB_L0 + 16>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
+  sp_segment<S, BFS_L1 + 128, 8, 16, 0, BFB_L0 + 16, 0, BFB_L0 + 24>(c, fr, acc, Yh, Ym, nullptr, nullptr, relu_to(Xh, Xm), last_of(relu_to(Yh, Ym), 7));
+  sp_segment<S, BFS_L1 + 256, 8, 16, 0, BFB_L0 + 24, 0, BFB_L0 + 32>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
+  sp_segment<S, BFS_L4, 8, 16, 4, BFB_L0 + 32, 0, BFB_L0 + 40>(c, fr, acc, Yh, Ym, gp_hi, gp_mid, relu_to(Xh, Xm), last_of(relu_to(Yh, Ym), 7));
+  sp_segment<S, BFS_L5, 8, 16, 0, BFB_L0 + 40, 0, BFB_L0 + 48>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
+  sp_segment<S, BFS_L5 + 128, 8, 16, 0, BFB_L0 + 48, 0, BFB_L0 + 56>(c, fr, acc, Yh, Ym, nullptr, nullptr, relu_to(Xh, Xm), last_of(relu_to(Yh, Ym), 7));
+  sp_segment<S, BFS_L5 + 256, 8, 16, 0, BFB_L0 + 56, 0, BFB_SIGMA>(c, fr, acc, Xh, Xm, nullptr, nullptr, relu_to(Yh, Ym), last_of(relu_to(Xh, Xm), 7));
   // ---- sigma head (one tile, row 0) on h7: sigma = |w_sigma . h7 + b|  (nerf.py:94, 113-115)
   float spre = 0.f;
   auto sig_epi = [&](int part, int ph, const f32x16& A, EpiTmp&) { if (part == 0 && ph == 0) spre = A[0]; };
-  sp_segment<S, BFS_SIG, 1, 16, 0, BFB_SIGMA, 0, BFB_DIR>(c, fr, acc, Yh, Ym, nullptr, nullptr, nothing_f, last_of(e7, 7));
+  sp_segment<S, BFS_SIG, 1, 16, 0, BFB_SIGMA, 0, BFB_DIR>(c, fr, acc, Yh, Ym, nullptr, nullptr, nothing_f, last_of(relu_to(Yh, Ym), 7));
   // ---- point_info folded into dir_info: c = relu(W_dir[:, :24] gamma_d + W_fold h7 + b_dir + W_dir[:, 24:] b_pi)  (nerf.py:117-118)
-  sp_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd_hi, gd_mid, Yh, Ym, ec, sig_epi);
-  if (SAVE && valid && h == 0) a.spre[a.row0 + m] = spre;
+  sp_segment<S, BFS_DIR, 4, 2, 16, BFB_DIR, 1, BFB_COL>(c, fr, acc, gd_hi, gd_mid, Yh, Ym, relu_to(Xh, Xm), sig_epi);
   if (valid && h == 0) a.sigma[m] = fabsf(spre);
   // ---- colour head: rows 0..2 of one tile, sigmoid (nerf.py:99, 119)
-  sp_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, Xh, Xm, nullptr, nullptr, nothing_f, last_of(ec, 3));
+  sp_segment<S, BFS_COL, 1, 8, 0, BFB_COL, 1, -1>(c, fr, acc, Xh, Xm, nullptr, nullptr, nothing_f, last_of(relu_to(Xh, Xm), 3));
   if (valid && h == 0) {
     a.rgb[(size_t)m * 3 + 0] = 1.0f / (1.0f + expf(-acc[1][0]));
     a.rgb[(size_t)m * 3 + 1] = 1.0f / (1.0f + expf(-acc[1][1]));
@@ -356,17 +271,11 @@ hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsi
   return hipGetLastError();
 }
 
-hipError_t launch_field_fwd_split(const FieldArgs& a, bool save, hipStream_t st) {
-  static std::atomic<unsigned long long> opted{0}, opted_save{0};
+hipError_t launch_field_fwd_split(const FieldArgs& a, hipStream_t st) {
+  static std::atomic<unsigned long long> opted{0};
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_split)}, BF_LDS_BYTES)) return e;
   const int wgs = (a.M + SP_WG / 2 - 1) / (SP_WG / 2);
-  if (save) {
-    if (!a.save || !a.masks || !a.spre) return hipErrorInvalidValue;
-    if (hipError_t e = ensure_dynamic_lds(opted_save, {reinterpret_cast<const void*>(&k_field_fwd_split<true>)}, BF_LDS_BYTES)) return e;
-    hipLaunchKernelGGL(k_field_fwd_split<true>, dim3(wgs), dim3(SP_WG), BF_LDS_BYTES, st, a);
-  } else {
-    if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_fwd_split<false>)}, BF_LDS_BYTES)) return e;
-    hipLaunchKernelGGL(k_field_fwd_split<false>, dim3(wgs), dim3(SP_WG), BF_LDS_BYTES, st, a);
-  }
+  hipLaunchKernelGGL(k_field_fwd_split, dim3(wgs), dim3(SP_WG), BF_LDS_BYTES, st, a);
   return hipGetLastError();
 }
 

@@ -149,7 +149,7 @@ hipError_t launch_pack_weights_bf16x(const Weights24& w, const float* fold, unsi
 // split-fp32 inference (field_fwd_split.hip): fp32 operands as two bf16 parts, three bf16 MFMAs per product
 size_t split_image_bytes();
 hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
-hipError_t launch_field_fwd_split(const FieldArgs& a, bool save, hipStream_t st);  // save: + the fp32 rows / masks / spre the exact-fp32 backward reads (FieldArgs)
+hipError_t launch_field_fwd_split(const FieldArgs& a, hipStream_t st);
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
 // bf16 paths: fold + packed image(s) + ray records in ONE launch (prep_bf16.hip).  img_fwd: forward image (fwd_form 0: 32x32x16 stream,
 // 1: 16x16x32) or null = weights unchanged; img_bwd: transposed image of the backward chain or null; ready: PREP_READY_WORDS u32 words of the

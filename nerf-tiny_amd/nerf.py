@@ -74,11 +74,9 @@ class ResampleIndexError(RuntimeError):
 
 def _call_flags(model, need_grad: bool) -> int:
     bf16 = getattr(model, "bf16_mlp", False)
-    # split-fp32: `split_mlp` selects it for inference calls, `split_train` (opt-in, its own switch) for the FORWARD of training calls -- the
-    # backward then runs the exact-fp32 chain / weight-gradient kernels on what that forward saved
-    split = getattr(model, "split_train", False) and not model.force_tile_kernel if need_grad else getattr(model, "split_mlp", False)
     return ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
-            | (_abi.BF16_MLP if bf16 else 0) | (_abi.SPLIT_MLP if split and not bf16 else 0))
+            | (_abi.BF16_MLP if bf16 else 0)
+            | (_abi.SPLIT_MLP if getattr(model, "split_mlp", False) and not need_grad and not bf16 else 0))  # inference only
 
 
 class _RenderFn(torch.autograd.Function):
@@ -173,10 +171,6 @@ class NeRFModel(nn.Module):
         #: and three MFMAs per product, fp32 accumulation -- inside the same 1e-4 bar as the exact-fp32 default,
         #: 3x faster.  Off by default: the default keeps exact k-ordered fp32 fma chains; training forwards ignore it
         self.split_mlp = False
-        #: TRAINING calls (forward that records a graph, train_step): run the FORWARD on the split-fp32 kernel (same 1e-4 bar for C_coarse /
-        #: C_fine, loss to 1e-5), saving the fp32 rows / masks the exact-fp32 backward kernels read.  Opt-in, never the headline: the default
-        #: keeps the exact fp32 forward; the gradients stay inside the bands the exact path is held to (tests/test_gpu_split.py)
-        self.split_train = False
         #: parallel.GradBucket or None.  When set (read when the forward records the graph), backward writes the 24 gradients straight
         #: into the bucket's flat buffer and makes p.grad its views (overwrite semantics: one backward per step, a second one before
         #: the gradients were consumed raises; autograd.grad / hooks unsupported), so the all-reduce needs no pack / unpack
@@ -245,7 +239,6 @@ class NeRFModel(nn.Module):
         super().__setstate__(d)
         self.__dict__.setdefault("grad_bucket", None)
         self.__dict__.setdefault("split_mlp", False)
-        self.__dict__.setdefault("split_train", False)
         self.__dict__["_ws"], self.__dict__["_ws_generation"] = {}, {}
         self.__dict__["_last_ws"], self.__dict__["_packed"], self.__dict__["_frozen"] = None, set(), False
         self.__dict__["_ws_capacity"] = False
