@@ -42,8 +42,8 @@
 extern "C" {
 #endif
 
-#define NERF_HIP_ABI_VERSION 5 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap, NERF_HIP_SPLIT_MLP;
-                                  4: nerf_hip_read_status_sticky; 5: nerf_hip_train_step */
+#define NERF_HIP_ABI_VERSION 6 /* 2: NERF_HIP_BF16_MLP, nerf_hip_field_bf16; 3: nerf_hip_backward_overlap, NERF_HIP_SPLIT_MLP;
+                                  4: nerf_hip_read_status_sticky; 5: nerf_hip_train_step; 6: NERF_HIP_CORRECTED */
 
 enum {
   NERF_HIP_OK = 0,
@@ -72,6 +72,14 @@ enum {
                                           MFMAs per product, fp32 accumulation -- within the same 1e-4 bar as the exact-fp32 default
                                           (measured 3e-6 / 2e-5 against the reference's outputs), several times faster; opt-in because
                                           the default keeps exact k-ordered fp32 fma chains.  Ignored with NERF_HIP_BF16_MLP */
+  NERF_HIP_CORRECTED = 1 << 5,         /* OPTIONAL EXTRA, off by default, NOT the reference's results (SURVEY.md 8a "Q": reproduce the quirks by
+                                          default, offer a flagged corrected mode): (Q1) the merged samples are sorted ONCE, by depth, stably, and
+                                          rgb / sigma move with their sample, instead of nerf.py:307-308's five independent channel sorts; (Q9) t_fine
+                                          is treated as detached: no gradient flows through the fine depths (neither through the sample positions
+                                          nor through the merged deltas) into the coarse pass, instead of nerf.py:259's attached t_fine.  Every other
+                                          quirk (Q2-Q8, Q10-Q12) stays.  Pass the same flag to forward and backward.  Parity of this mode is
+                                          UNPINNED (the reference has no such mode): it is tested against the oracle's restatement of the same
+                                          two changes only */
 };
 
 /* status word bits (nerf_hip_read_status) */

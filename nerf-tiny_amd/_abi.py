@@ -11,12 +11,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_HIP_LIB", os.path.join(_HERE, "libnerf_hip.so"))  # override: diagnostic builds only
 
-NERF_HIP_ABI_VERSION = 5
+NERF_HIP_ABI_VERSION = 6
 SAVE_FOR_BACKWARD = 1 << 0
 FORCE_TILE_KERNEL = 1 << 1
 BF16_MLP = 1 << 2
 WEIGHTS_UNCHANGED = 1 << 3
 SPLIT_MLP = 1 << 4
+CORRECTED = 1 << 5
 STATUS_RESAMPLE_INDEX = 1 << 0
 STATUS_PREP_TIMEOUT = 1 << 1
 

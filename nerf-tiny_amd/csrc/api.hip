@@ -352,7 +352,8 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   const bool one_prep = bf16 && !split && !prep_bf16_disabled();
   // SMALL bf16-MLP inference batches at the shipped sample counts: ONE launch renders every ray pair end to end, ray records included
   // (field_fwd_bf16x.hip: k_render_pair_bf16x); with the weight image reused (rendering loops) it is the only launch of the call
-  const bool pair = bf16x && Nc == 64 && Nf == 128 && pair_bf16(B);
+  const bool corrected = (flags & NERF_HIP_CORRECTED) != 0;  // joint depth sort (forward); the fused small-batch forms keep the reference's sorts only
+  const bool pair = bf16x && Nc == 64 && Nf == 128 && pair_bf16(B) && !corrected;
   if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED) && !one_prep) {
     ProfScope ps(NERF_HIP_K_PACK, st, &pc);
     if (bf16 || split) HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));  // fp32 W_fold, b_fold for the bf16 / split packers (bf16_common.h)
@@ -436,7 +437,7 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
     return NERF_HIP_OK;
   }
   // SMALL bf16 TRAINING batches at the shipped sample counts: k_coarse / k_merge ride as epilogues of the field launches (kernels.h FwdFuse)
-  const bool fuse_rays = bf16 && save && Nc == 64 && Nf == 128 && fuse_rays_bf16(B);
+  const bool fuse_rays = bf16 && save && Nc == 64 && Nf == 128 && fuse_rays_bf16(B) && !corrected;
   FwdFuse ff;
   memset(&ff, 0, sizeof(ff));
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
@@ -474,6 +475,7 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   ma.rgb_c = at<float>(ws, L.rgb_c); ma.rgb_f = at<float>(ws, L.rgb_f);
   ma.B = B; ma.Nc = Nc; ma.Nf = Nf; ma.P = next_pow2(Nc + Nf);
   ma.last = last_delta;
+  ma.joint = corrected ? 1 : 0;
   if (save) { ma.bundle = at<float>(ws, L.bundle); ma.w = at<float>(ws, L.w_m); ma.perm = at<uint16_t>(ws, L.perm); }
   ma.C_fine = C_fine;
   if (fuse_rays) {
@@ -585,7 +587,8 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   mb.drgb_c = at<float>(ws, L.drgb_c); mb.dsig_c = at<float>(ws, L.dsig_c);
   mb.drgb_f = at<float>(ws, L.drgb_f); mb.dsig_f = at<float>(ws, L.dsig_f); mb.dt_f = at<float>(ws, L.dt_f);
   // SMALL bf16 batches: the per-ray backward stages ride as prologues of the chain launches (kernels.h BwdFuse)
-  const bool fuse_rays = bf16 && Nc == 64 && Nf == 128 && fuse_rays_bf16(B);
+  const bool corrected = (flags & NERF_HIP_CORRECTED) != 0;
+  const bool fuse_rays = bf16 && Nc == 64 && Nf == 128 && fuse_rays_bf16(B) && !corrected;  // (must agree with the forward's choice)
   BwdFuse bz;
   memset(&bz, 0, sizeof(bz));
   if (!fuse_rays) { ProfScope ps(NERF_HIP_K_BWD_MERGE, st, &pc); HIP_TRY(launch_merge_bwd(mb, st)); }
@@ -617,6 +620,9 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   }
   { ProfScope ps(NERF_HIP_K_BWD_FIELD_FINE, st, &pc); HIP_TRY(chain(fb, true)); }
   bz.mode = 0;
+  // NERF_HIP_CORRECTED: t_fine detached -- what the merge backward (deltas) and the fine chain (sample positions) left in d loss / d t_fine is
+  // dropped before the resampling backward reads it, so the coarse pass receives the gradient of C_coarse alone
+  if (corrected) HIP_TRY(hipMemsetAsync(at<float>(ws, L.dt_f), 0, (size_t)B * Nf * sizeof(float), st));
 
   // 3. resampling + coarse composite backward (nerf.py:225-261, 263-281)
   CoarseBwdArgs cb;

@@ -103,6 +103,8 @@ struct MergeArgs {
   float* w;        // [B][N] or null
   uint16_t* perm;  // [B][5][N] or null: sorted position -> original index (coarse first, then fine)
   float* C_fine;   // [B][3]
+  int joint;       // NERF_HIP_CORRECTED: ONE stable sort by depth whose permutation moves all five channels (rgb and sigma stay with their
+                   // sample) instead of the reference's five independent channel sorts (quirk Q1); perm then holds that permutation five times
 };
 
 // SMALL bf16 training batches (Nc = 64, Nf = 128): the per-ray stages ride in the field kernels instead of launches of their own --

@@ -91,7 +91,7 @@ hipError_t launch_coarse(const CoarseArgs& a, hipStream_t st) {
 size_t merge_lds_bytes(int P) { return (size_t)5 * P * (sizeof(float) + sizeof(uint16_t)); }
 hipError_t launch_merge(const MergeArgs& a, hipStream_t st) {
   const size_t lds = merge_lds_bytes(a.P);
-  if (a.perm) {
+  if (a.perm || a.joint) {  // (the joint-sort mode needs the depth channel's permutation, stored or not)
     if (lds > 48 * 1024)
       if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     hipLaunchKernelGGL(k_merge<true>, dim3(a.B), dim3(64), lds, st, a);

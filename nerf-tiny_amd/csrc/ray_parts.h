@@ -290,9 +290,10 @@ __device__ __forceinline__ void merge_ray_composite(const float* val, const uint
 // nerf.py:302-321 behind the load: val [5][P] (channel 0 = t, 1..3 = rgb, 4 = sigma; slots >= N padded with NaN) and, WITH_IDX, idx [5][P]
 // = the original slot, in LDS -> five independent ascending channel sorts (quirk Q1), delta_i = t_{i+1} - t_i with the last = `last`,
 // weights, C_fine[3]; optionally w [N], the sorted bundle [N][5] and the permutations perm [5][N] (global).
-template <bool WITH_IDX, class Sync>
+struct MergeNoFix { __device__ __forceinline__ void operator()() const {} };
+template <bool WITH_IDX, class Sync, class PostSort = MergeNoFix>
 __device__ __forceinline__ void merge_ray_sort_composite(float* val, uint16_t* idx, int P, int N, float last, int lane, float* w_out, float* bundle_out,
-                                                         uint16_t* perm_out, float* C_out, Sync&& sync) {
+                                                         uint16_t* perm_out, float* C_out, Sync&& sync, PostSort&& post_sort = MergeNoFix{}) {
   if (P == 256) {  // the usual size (64 + 128 samples): the whole network in registers
     sort256_regs<WITH_IDX>(val, idx, lane, sync);
   } else
@@ -325,6 +326,7 @@ __device__ __forceinline__ void merge_ray_sort_composite(float* val, uint16_t* i
       sync();
     }
   }
+  post_sort();  // (the joint-sort mode re-fills channels 1..4 by the depth channel's permutation here)
   merge_ray_composite<WITH_IDX>(val, idx, P, N, last, lane, w_out, bundle_out, perm_out, C_out);
 }
 
@@ -431,8 +433,25 @@ __device__ __forceinline__ void merge_ray_stage(const MergeArgs& a, const int ra
   }
   sync();
   const size_t gN = (size_t)ray * N;
+  // NERF_HIP_CORRECTED (a.joint; WITH_IDX only): the five channels were sorted independently above like the reference's (quirk Q1); the joint
+  // mode keeps the DEPTH channel's stable sort and lets its permutation carry rgb and sigma along -- the other four sorts are overwritten
+  auto joint_fix = [&]() {
+    if constexpr (WITH_IDX) {
+      if (a.joint) {
+        for (int i = lane; i < P; i += 64) {
+          const int slot = idx[i];
+#pragma unroll
+          for (int c = 1; c < 5; ++c) {
+            val[c * P + i] = merge_slot_value(a, ray, c, slot);
+            idx[c * P + i] = (uint16_t)slot;
+          }
+        }
+        sync();
+      }
+    }
+  };
   merge_ray_sort_composite<WITH_IDX>(val, idx, P, N, a.last, lane, a.w ? a.w + gN : nullptr, a.bundle ? a.bundle + gN * 5 : nullptr,
-                                     (WITH_IDX && a.perm) ? a.perm + (size_t)ray * 5 * N : nullptr, a.C_fine + (size_t)ray * 3, sync);
+                                     (WITH_IDX && a.perm) ? a.perm + (size_t)ray * 5 * N : nullptr, a.C_fine + (size_t)ray * 3, sync, joint_fix);
 }
 
 // ---- ray_loss (nerf.py:325-331) in two pieces, bit-compatible with k_ray_loss (ray_ops.hip) ----

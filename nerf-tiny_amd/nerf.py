@@ -75,7 +75,7 @@ class ResampleIndexError(RuntimeError):
 def _call_flags(model, need_grad: bool) -> int:
     bf16 = getattr(model, "bf16_mlp", False)
     return ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
-            | (_abi.BF16_MLP if bf16 else 0)
+            | (_abi.BF16_MLP if bf16 else 0) | (_abi.CORRECTED if getattr(model, "corrected", False) else 0)
             | (_abi.SPLIT_MLP if getattr(model, "split_mlp", False) and not need_grad and not bf16 else 0))  # inference only
 
 
@@ -171,6 +171,10 @@ class NeRFModel(nn.Module):
         #: and three MFMAs per product, fp32 accumulation -- inside the same 1e-4 bar as the exact-fp32 default,
         #: 3x faster.  Off by default: the default keeps exact k-ordered fp32 fma chains; training forwards ignore it
         self.split_mlp = False
+        #: OPTIONAL EXTRA, off by default, NOT the reference's results (SURVEY.md 8a "Q"): one stable sort of the merged samples by depth with
+        #: rgb / sigma moving along (instead of nerf.py:307-308's five independent channel sorts) and a detached t_fine (instead of
+        #: nerf.py:259's attached one).  Parity unpinned -- the reference has no such mode; tested against the oracle's restatement only
+        self.corrected = False
         #: parallel.GradBucket or None.  When set (read when the forward records the graph), backward writes the 24 gradients straight
         #: into the bucket's flat buffer and makes p.grad its views (overwrite semantics: one backward per step, a second one before
         #: the gradients were consumed raises; autograd.grad / hooks unsupported), so the all-reduce needs no pack / unpack
@@ -239,6 +243,7 @@ class NeRFModel(nn.Module):
         super().__setstate__(d)
         self.__dict__.setdefault("grad_bucket", None)
         self.__dict__.setdefault("split_mlp", False)
+        self.__dict__.setdefault("corrected", False)
         self.__dict__["_ws"], self.__dict__["_ws_generation"] = {}, {}
         self.__dict__["_last_ws"], self.__dict__["_packed"], self.__dict__["_frozen"] = None, set(), False
         self.__dict__["_ws_capacity"] = False

@@ -255,10 +255,12 @@ def resample(t_c: torch.Tensor, w_c: torch.Tensor, n_fine: int, check: bool = Tr
     return t_f, dict(cdf=cdf, u=u, k=k, bad=bad)
 
 
-def render(params, row, col, poses_bound, K_inv, n_coarse=64, n_fine=128, last=LAST_DELTA, stages=None, check=True, mlp=None):
+def render(params, row, col, poses_bound, K_inv, n_coarse=64, n_fine=128, last=LAST_DELTA, stages=None, check=True, mlp=None, corrected=False):
     """nerf.py:333-348 + 286-323.  Returns (C_coarse[B,3], C_fine[B,3]).  ``stages`` (a dict) receives
     every intermediate.  Needs B >= 2 like the reference (quirk Q7: B = 1 breaks .squeeze()).
-    ``mlp``: the field network; default = the reference's fp32 ``mlp`` (``mlp_bf16`` for the cfg3 variant)."""
+    ``mlp``: the field network; default = the reference's fp32 ``mlp`` (``mlp_bf16`` for the cfg3 variant).
+    ``corrected`` (NOT the reference; the flagged extra of SURVEY.md 8a "Q", parity unpinned): t_fine detached (vs nerf.py:259) and ONE
+    stable sort by depth that carries rgb / sigma along (vs the five independent channel sorts of nerf.py:307-308)."""
     mlp = mlp or globals()["mlp"]
     f_p, f_d = frequencies()
     R, o, near, far = poses_extract(poses_bound)
@@ -273,13 +275,20 @@ def render(params, row, col, poses_bound, K_inv, n_coarse=64, n_fine=128, last=L
     w_c = weights_from_sigma(delta_c, sig_c)
 
     t_f, rs = resample(t_c, w_c, n_fine, check=check)
+    if corrected:
+        t_f = t_f.detach()
     pts_f = sample_points(R, o, d_cam, t_f)
     rgb_f, sig_f = mlp(params, encode(pts_f, f_p), gd[:, None, :].expand(-1, n_fine, -1))
 
     # nerf.py:302-308: ONE sort over dim=1 of a [B,N,5] bundle => five independent channel sorts (Q1)
     bundle = torch.cat((torch.cat((t_c, t_f), 1).unsqueeze(2), torch.cat((rgb_c, rgb_f), 1),
                         torch.cat((sig_c, sig_f), 1).unsqueeze(2)), dim=2)
-    sb, perm = torch.sort(bundle, dim=1)
+    if corrected:
+        perm_t = torch.sort(bundle[:, :, 0], dim=1, stable=True)[1]
+        perm = perm_t.unsqueeze(2).expand(-1, -1, 5)
+        sb = torch.gather(bundle, 1, perm)
+    else:
+        sb, perm = torch.sort(bundle, dim=1)
     t_s, rgb_s, sig_s = sb[:, :, 0], sb[:, :, 1:4], sb[:, :, 4]
     delta = torch.cat((t_s[:, 1:] - t_s[:, :-1], torch.full((t_s.shape[0], 1), last)), dim=1)
     w = weights_from_sigma(delta, sig_s)
@@ -297,11 +306,11 @@ def ray_loss(C_c, C_f, C_true):
     return torch.sum(torch.square(C_c - C_true)) + torch.sum(torch.square(C_f - C_true))
 
 
-def loss_and_grads(params, row, col, poses_bound, K_inv, C_true, n_coarse=64, n_fine=128):
+def loss_and_grads(params, row, col, poses_bound, K_inv, C_true, n_coarse=64, n_fine=128, corrected=False):
     """Forward + autograd backward of the restatement (nerf.py:470-473).  Returns
     (C_c, C_f, loss, grads: OrderedDict name -> tensor)."""
     p = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in params.items())
-    C_c, C_f = render(p, row, col, poses_bound, K_inv, n_coarse, n_fine)
+    C_c, C_f = render(p, row, col, poses_bound, K_inv, n_coarse, n_fine, corrected=corrected)
     loss = ray_loss(C_c, C_f, C_true)
     loss.backward()
     return C_c.detach(), C_f.detach(), loss.detach(), OrderedDict((k, v.grad) for k, v in p.items())

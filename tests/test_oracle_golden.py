@@ -92,6 +92,25 @@ def test_oracle_reproduces_the_references_decisions(oracle, name):
             assert l2_rel(v.grad, g["grad_" + kk]) < 0.3, kk
 
 
+def test_corrected_mode_of_the_oracle(oracle):
+    """the flagged extra (SURVEY.md 8a "Q"; parity unpinned -- the reference has no such mode): joint depth sort + detached t_fine.  With ONE
+    permutation per ray the sorted sigma / rgb are the samples' own; the coarse colour is unchanged; with a loss on C_fine alone the gradient
+    equals the default mode's whenever nothing flows through t_fine and the channel sorts happen to agree -- here only the structure is
+    checked: same C_coarse, another C_fine, finite gradients, the permutation identical across channels."""
+    row, col, pb, K, Ct = oracle.lego_inputs(48, seed=2)
+    w = oracle.make_weights(1, sharp=True)
+    st0, st1 = {}, {}
+    with torch.no_grad():
+        Cc0, Cf0 = oracle.render(w, row, col, pb, K, 64, 128, stages=st0)
+        Cc1, Cf1 = oracle.render(w, row, col, pb, K, 64, 128, stages=st1, corrected=True)
+    assert torch.equal(Cc0, Cc1) and not torch.equal(Cf0, Cf1)
+    assert all(torch.equal(st1["perm"][:, :, c], st1["perm"][:, :, 0]) for c in range(5))
+    assert torch.equal(st1["t_s"], st0["t_s"])  # the depth channel is sorted the same way in both modes
+    assert not torch.equal(st1["sig_s"], st0["sig_s"])
+    _, _, loss, grads = oracle.loss_and_grads(w, row, col, pb, K, Ct, 64, 128, corrected=True)
+    assert torch.isfinite(loss) and all(torch.isfinite(v).all() for v in grads.values())
+
+
 def test_frequencies_bits(oracle):
     """quirk Q3: non-integer octaves; bit patterns baked into csrc/common.h."""
     fp, fd = oracle.frequencies()
