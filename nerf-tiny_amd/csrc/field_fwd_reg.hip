@@ -112,6 +112,16 @@ __device__ __forceinline__ void reg_layer(const int seg, const int next_seg /* f
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(cur.w[f], s), b, acc[f], 0, 0, 0);
       }
     }
+#ifdef NERF_FWD_SAVE_SPREAD  // (variant build under measurement, VERDICT round 4 item 6: the activation's stores one per 8 MFMAs instead of one burst)
+    if (SAVE && NFT == 8 && (kb & 3) == 2 && (kb >> 2) + 1 < KT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);  // the VALU work of a quarter of the tile
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // 1 vector-memory store
+      }
+    }
+#endif
   }
   if (KB & 1) st0 = st1;  // (all segments have an even number of k-blocks: the next k-block 0 already sits in st0)
 }
