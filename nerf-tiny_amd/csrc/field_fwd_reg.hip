@@ -112,7 +112,8 @@ __device__ __forceinline__ void reg_layer(const int seg, const int next_seg /* f
           acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(cur.w[f], s), b, acc[f], 0, 0, 0);
       }
     }
-#ifdef NERF_FWD_SAVE_SPREAD  // (variant build under measurement, VERDICT round 4 item 6: the activation's stores one per 8 MFMAs instead of one burst)
+#ifdef NERF_FWD_SAVE_SPREAD  // (variant build only -- `make variant NAME=spread DEFS=-DNERF_FWD_SAVE_SPREAD`: the activation's stores one per 8 MFMAs instead of
+                             // one burst.  Measured round 5: +10 % on this kernel -- 865 instead of 131 s_nops of hazard padding per tile)
     if (SAVE && NFT == 8 && (kb & 3) == 2 && (kb >> 2) + 1 < KT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
