@@ -625,6 +625,8 @@ def compact_line(full, side_path=None):
         ring = full.get("implied_strong_scaling_8_with_ring_estimate")
         if isinstance(ring, dict) and ring:
             line["implied_strong_scaling_8_with_ring_estimate_min"] = min(ring.values())
+    if "rehearsal" in full:
+        line["rehearsal"] = cut(full["rehearsal"], 120)
     if side_path is not None:
         line["side_file"] = os.path.basename(side_path)
     n = len(json.dumps(line, separators=(",", ":")))
@@ -715,6 +717,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     _abi.lib()  # fail loudly if the HIP library is missing
+    # BENCH_DIST_BACKEND=gloo (tests only): rehearse the N-rank code path -- sharding, global ray 0, strong legs, MAX reduction, the compact line
+    # with its strong_* scalars -- with N ranks SHARING the GPUs there are (RCCL refuses two ranks on one device; gloo moves the bucket through
+    # the host).  The line it prints measures nothing and is marked "rehearsal".
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -731,7 +739,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", str(_free_port()))  # only the single-rank rehearsal comes without a launcher's environment
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     world = dist.get_world_size() if dist is not None else 1
 
     strong = args.scaling == "strong"
@@ -932,6 +940,8 @@ def main():
                        f"ray-batch DP x{world} (one flat SUM all-reduce of 593,924 fp32 gradients per step)"},
             "roofline": rep["roofline"],
             "whole_path_tflops": rep["whole_path_tflops_per_gpu"],  # per GPU
+            **({"rehearsal": "BENCH_DIST_BACKEND=gloo: ranks share the GPU(s), the collective goes through the host -- the code path, not a measurement"}
+               if backend == "gloo" and dist is not None else {}),
             "kernel_ms_per_step": rep["kernel_ms_per_step"],
         }
         for k in ("roofline_phases", "allreduce_ms", "allreduce"):

@@ -110,6 +110,25 @@ def test_bench_default_line_carries_the_per_rank_proxy(tmp_path):
         assert 0.9 * leg["ms_per_step_with_kernel_events"] < leg["ms_per_step"] < 1.05 * leg["ms_per_step_with_kernel_events"], (name, leg)
 
 
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_rehearsed_on_one_gpu(tmp_path):
+    """The driver's N > 1 command (`python bench.py --gpus 2 ...`: this process launches the ranks itself) has never met a multi-GPU node.
+    Rehearsed here with BOTH ranks on the one GPU of the box and gloo in RCCL's place (BENCH_DIST_BACKEND=gloo): the launcher, per-rank
+    inputs, weak legs, the strong legs (one 4,096-ray batch split 2,048 / 2,048, the global ray 0's spacing forwarded to rank 1), the flat SUM
+    all-reduce, the MAX reduction of the times, rank 0's compact line with its strong_* scalars -- the code path, not a measurement."""
+    env = _env()
+    env["BENCH_DIST_BACKEND"] = "gloo"
+    line, full = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env, tmp_path)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "rehearsal" in line
+    assert line["config"]["rays_per_step_per_gpu"] == 4096 and line["value"] > 0
+    for k in ("train_f32_rays_per_s", "train_bf16_rays_per_s", "strong_train_f32_rays_per_s", "strong_train_bf16_rays_per_s",
+              "strong_forward_f32_rays_per_s", "strong_forward_bf16_rays_per_s", "strong_train_bf16_allreduce_ms"):
+        assert line.get(k) is not None, k
+    assert full["extra"]["strong_train_f32"]["rays_per_step"] == 4096
+    assert "per_rank_proxy" not in full and "cpu_baseline" not in full  # N = 1 only
+    assert full["parity"]["pass"] is True
+
+
 def _run_ranks(n, out, extra=(), backend=None, timeout=500):
     """n ranks of tests/tools/dp_runner_rank.py under torch.distributed.run (n = 0: the plain single-process runner), fresh processes."""
     import socket
