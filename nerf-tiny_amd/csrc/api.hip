@@ -173,6 +173,19 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
       L.bG = take(wb * BG_TOTAL_KS * BF_FRAG_BYTES);
       L.bslabs = take(dw_bf16_slab_floats() * 4);
       L.mbuf = take((size_t)HALF * WIDTH * 4);
+    } else if (flags & NERF_HIP_SPLIT_MLP) {
+      // split-fp32 training: the bf16 variant's fragment-layout buffers twice (hi parts, mid parts); the weight-gradient products run three
+      // times over them (hi x hi, hi x mid, mid x hi) into three gradient sets that are summed at the end
+      const size_t wb = wave_blocks(B, Nc) + wave_blocks(B, Nf);
+      L.packed_sp_bwd = take(split_bwd_image_bytes());
+      L.bsave = take(wb * BS_TOTAL_KS * BF_FRAG_BYTES);
+      L.bsave2 = take(wb * BS_TOTAL_KS * BF_FRAG_BYTES);
+      L.bmask = take(wb * BM_LAYERS * 1024);
+      L.bG = take(wb * BG_TOTAL_KS * BF_FRAG_BYTES);
+      L.bG2 = take(wb * BG_TOTAL_KS * BF_FRAG_BYTES);
+      L.bslabs = take(dw_bf16_slab_floats() * 4);
+      L.mbuf = take((size_t)3 * HALF * WIDTH * 4);
+      L.dwtmp = take((size_t)2 * SPLIT_GRAD_SET_FLOATS * 4);
     } else {
       L.save = take((size_t)NSAVE * (Mtot + DUMP_ROWS) * WIDTH * 4);  // + dump rows (kernels.h: MSrows)
       L.masks = take((size_t)8 * tiles * 4 * 256 * 2);
@@ -205,6 +218,14 @@ int check_device() {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(NERF_HIP_ERR_ARCH, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
   checked_dev = dev;
   return NERF_HIP_OK;
+}
+
+// elements of tensor t of weights24 / dweights24 (include/nerf_hip.h: NeRFModel.network.parameters() order)
+int param_numel(int t) {
+  static const int n[24] = {WIDTH * POINT_DIM, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH * (WIDTH + POINT_DIM), WIDTH,
+                            WIDTH * WIDTH, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH, 1, WIDTH * WIDTH, WIDTH, HALF * (WIDTH + DIR_DIM), HALF,
+                            3 * HALF, 3};
+  return n[t];
 }
 
 int check_weights(const float* const* w) {
@@ -343,7 +364,7 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   const bool bf16x = bf16 && !save && !(flags & NERF_HIP_FORCE_TILE_KERNEL);
   // split-fp32 inference (field_fwd_split.hip): fp32 operands as two bf16 parts, three bf16 MFMAs per product
   const bool split = (flags & NERF_HIP_SPLIT_MLP) && !bf16;
-  if (split && save) return fail(NERF_HIP_ERR_ARG, "NERF_HIP_SPLIT_MLP is an inference mode: not with NERF_HIP_SAVE_FOR_BACKWARD");
+  // (split && save: the opt-in split-fp32 TRAIN step -- forward with hi / mid fragment-layout saves, field_bwd_split.hip, three bf16 weight-gradient passes)
   const Weights24 w = as_w24(weights24);
 
   ProfChain pc;  // the phases below follow each other with nothing in between
@@ -357,8 +378,10 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   if (!(flags & NERF_HIP_WEIGHTS_UNCHANGED) && !one_prep) {
     ProfScope ps(NERF_HIP_K_PACK, st, &pc);
     if (bf16 || split) HIP_TRY(launch_fold_weights(w, at<float>(ws, L.fold), st));  // fp32 W_fold, b_fold for the bf16 / split packers (bf16_common.h)
-    if (split) HIP_TRY(launch_pack_weights_split(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_sp), st));
-    else
+    if (split) {
+      HIP_TRY(launch_pack_weights_split(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_sp), st));
+      if (save) HIP_TRY(launch_pack_weights_split_bwd(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_sp_bwd), st));
+    } else
     if (bf16 && bf16x) HIP_TRY(launch_pack_weights_bf16x(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
     else if (bf16) HIP_TRY(launch_pack_weights_bf16(w, at<float>(ws, L.fold), at<unsigned char>(ws, L.packed_bf), st));
     else HIP_TRY(launch_pack_weights(w, at<float>(ws, L.fold), at<float4>(ws, L.packed), save ? NSEG : NSEG_FWD, st));
@@ -414,8 +437,9 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   if (save) {
     fa.spre = at<float>(ws, L.spre);
     fa.row0 = 0; fa.tile0 = 0; fa.tiles_tot = tiles_c + tiles_f; fa.Mtot = (long long)B * (Nc + Nf); fa.MSrows = fa.Mtot + DUMP_ROWS;
-    if (bf16) {
+    if (bf16 || split) {
       fa.bsave = at<unsigned char>(ws, L.bsave); fa.bmask = at<uint16_t>(ws, L.bmask);
+      if (split) fa.bsave2 = at<unsigned char>(ws, L.bsave2);
       fa.wb0 = 0; fa.wb_tot = (int)(wave_blocks(B, Nc) + wave_blocks(B, Nf));
     } else {
       fa.save = at<float>(ws, L.save); fa.masks = at<uint16_t>(ws, L.masks);
@@ -441,7 +465,7 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   FwdFuse ff;
   memset(&ff, 0, sizeof(ff));
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  auto field = [&](const FieldArgs& f) { return split ? launch_field_fwd_split(f, st) : bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st, ff.mode ? &ff : nullptr) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
+  auto field = [&](const FieldArgs& f) { return split ? launch_field_fwd_split(f, save, st) : bf16x ? launch_field_fwd_bf16x(f, st) : bf16 ? launch_field_fwd_bf16(f, save, st, ff.mode ? &ff : nullptr) : tile_kernel ? launch_field_fwd(f, save, st) : launch_field_fwd_reg(f, save, st); };
 
   CoarseArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -562,6 +586,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   if (!dC_coarse || !dC_fine || !ws) return fail(NERF_HIP_ERR_ARG, "null argument");
   if (!(flags & NERF_HIP_SAVE_FOR_BACKWARD)) return fail(NERF_HIP_ERR_ARG, "backward needs a forward run with NERF_HIP_SAVE_FOR_BACKWARD");
   const bool bf16 = (flags & NERF_HIP_BF16_MLP) != 0;
+  const bool split = (flags & NERF_HIP_SPLIT_MLP) && !bf16;  // split-fp32 train step: field_bwd_split.hip + three bf16 weight-gradient passes
   const WsLayout L = layout(B, Nc, Nf, flags);
   if (ws_bytes < L.total) return fail(NERF_HIP_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
   if (int rc = check_device()) return rc;
@@ -601,6 +626,10 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   if (bf16) {
     fb.wbf = at<unsigned char>(ws, L.packed_bf_bwd); fb.bmask = at<uint16_t>(ws, L.bmask); fb.bG = at<unsigned char>(ws, L.bG);
     fb.wb_tot = wb_tot;
+  } else if (split) {
+    fb.wbf = at<unsigned char>(ws, L.packed_sp_bwd); fb.bmask = at<uint16_t>(ws, L.bmask);
+    fb.bG = at<unsigned char>(ws, L.bG); fb.bG2 = at<unsigned char>(ws, L.bG2);
+    fb.wb_tot = wb_tot;
   } else {
     fb.save = save; fb.masks = at<uint16_t>(ws, L.masks);
     fb.G = G; fb.dz = at<float>(ws, L.dz); fb.dspre = at<float>(ws, L.dspre);
@@ -613,7 +642,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   fb.drgb = at<float>(ws, L.drgb_f); fb.dsig = at<float>(ws, L.dsig_f); fb.dt = at<float>(ws, L.dt_f);
   fb.row0 = B * Nc; fb.tile0 = tiles_c; fb.N = Nf; fb.M = B * Nf; fb.wb0 = wb_c;
   const bool tile_kernel = (flags & NERF_HIP_FORCE_TILE_KERNEL) != 0;
-  auto chain = [&](const FieldBwdArgs& f, bool fine) { return bf16 ? launch_field_bwd_bf16(f, fine, st, bz.mode ? &bz : nullptr) : tile_kernel ? launch_field_bwd(f, fine, st) : launch_field_bwd_reg(f, fine, st); };
+  auto chain = [&](const FieldBwdArgs& f, bool fine) { return split ? launch_field_bwd_split(f, fine, st) : bf16 ? launch_field_bwd_bf16(f, fine, st, bz.mode ? &bz : nullptr) : tile_kernel ? launch_field_bwd(f, fine, st) : launch_field_bwd_reg(f, fine, st); };
   if (fuse_rays) {
     bz.mode = 1; bz.m = mb;
     if (tl && tl->fused) { bz.loss_terms = tl->terms; bz.loss = tl->loss; }  // block 0 of the fine chain adds up the loss's summands
@@ -643,10 +672,10 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st, &pc); HIP_TRY(chain(fb, false)); }
 
   // 5. weight gradients: dW = G^T X over all B*(Nc+Nf) samples
-  if (bf16) {
-    ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
-    const unsigned char* bs = at<unsigned char>(ws, L.bsave);
-    const unsigned char* bg = at<unsigned char>(ws, L.bG);
+  // the bf16 products over ONE pair of fragment-layout buffers (layer inputs `bs`, pre-activation gradients `bg`) into one set of 24 gradient
+  // tensors `dwp` and the folded product's M (`mbuf`); `fold`: finish with k_fold_grads.  The bf16-MLP variant calls it once; the split-fp32
+  // train step three times (hi x hi, hi x mid, mid x hi) and sums the sets.
+  auto dw_bf16_phase = [&](const unsigned char* bs, const unsigned char* bg, float* const* dwp, float* mbuf, void* ev, bool fold) -> int {
     float* slabs = at<float>(ws, L.bslabs);
     const float* const slab_limit = slabs + dw_bf16_slab_floats();  // checked by launch_dw_bf16_multi before it enqueues anything
     auto X = [&](int t) { return bs + (size_t)wb_tot * bs_cum(t) * BF_FRAG_BYTES; };
@@ -675,23 +704,23 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       pr[n++] = DwBfProd{Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), nullptr, 0};                              // 8: folded dir_info product + sigma head
       pr[n++] = DwBfProd{Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, nullptr, 0};                                       // 9: colour head
       auto early_reds = [&]() {
-        red(pr[0].slabs, pr[0].nslab, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1]);
-        for (int k = 0; k < 6; ++k) red(pr[1 + k].slabs, pr[1 + k].nslab, 256, 256, 0, 256, 0, WIDTH, dw[2 * layers[k]], WIDTH, 0, dw[2 * layers[k] + 1]);
-        red(pr[7].slabs, pr[7].nslab, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
+        red(pr[0].slabs, pr[0].nslab, 256, 64, 0, 256, 0, POINT_DIM, dwp[0], POINT_DIM, 0, dwp[1]);
+        for (int k = 0; k < 6; ++k) red(pr[1 + k].slabs, pr[1 + k].nslab, 256, 256, 0, 256, 0, WIDTH, dwp[2 * layers[k]], WIDTH, 0, dwp[2 * layers[k] + 1]);
+        red(pr[7].slabs, pr[7].nslab, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dwp[8], WIDTH + POINT_DIM, 0, dwp[9]);
       };
       auto late_reds = [&]() {
-        red(pr[8].slabs, pr[8].nslab, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR]);
-        red(pr[8].slabs, pr[8].nslab, 160, 288, 0, HALF, 32, WIDTH, at<float>(ws, L.mbuf), WIDTH, 0, nullptr);
-        red(pr[8].slabs, pr[8].nslab, 160, 288, HALF + 3, 1, 32, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr);
-        red(pr[9].slabs, pr[9].nslab, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR]);
-        red(pr[9].slabs, pr[9].nslab, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA]);
+        red(pr[8].slabs, pr[8].nslab, 160, 288, 0, HALF, 0, DIR_DIM, dwp[W_DIR], WIDTH + DIR_DIM, 0, dwp[B_DIR]);
+        red(pr[8].slabs, pr[8].nslab, 160, 288, 0, HALF, 32, WIDTH, mbuf, WIDTH, 0, nullptr);
+        red(pr[8].slabs, pr[8].nslab, 160, 288, HALF + 3, 1, 32, WIDTH, dwp[W_SIGMA], WIDTH, 0, nullptr);
+        red(pr[9].slabs, pr[9].nslab, 32, 128, 0, 3, 0, HALF, dwp[W_COLOR], HALF, 0, dwp[B_COLOR]);
+        red(pr[9].slabs, pr[9].nslab, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dwp[B_SIGMA]);
       };
       float* end = slabs;
-      if (early_event) {
+      if (ev) {
         HIP_TRY(launch_dw_bf16_multi(pr, n_early, wb_tot, slabs, slab_limit, &end, st));
         early_reds();
         HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
-        HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(early_event), st));
+        HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev), st));
         rb.n = 0;
         HIP_TRY(launch_dw_bf16_multi(pr + n_early, n - n_early, wb_tot, end, slab_limit, &end, st));
         late_reds();
@@ -702,9 +731,9 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       }
       HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
       FoldGradArgs fg;
-      fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
-      fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
-      HIP_TRY(launch_fold_grads(fg, st));
+      fg.M = mbuf; fg.db_dir = dwp[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
+      fg.dW_pi = dwp[W_PI]; fg.db_pi = dwp[B_PI]; fg.dW_dir = dwp[W_DIR];
+      if (fold) HIP_TRY(launch_fold_grads(fg, st));
       return NERF_HIP_OK;
     }
     // LARGE batches, the products with SMALL blocks (layer 0: 20 KiB per wave block, the folded dir_info product 28, the colour head 10): alone
@@ -712,7 +741,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
     // profiles/r03_train_bf16_pmc.json); sharing ONE launch (k_dw_bf16_multi, workgroups dealt out by cost) their streams overlap.
     // Variant 1: six | layer 4 | {layer 0, folded, colour}; 2: six | {layer 4, layer 0, folded, colour}; 0: a launch each (round 3).
     // Without an early event only (the overlap needs layer 0 in front of the event and the other two behind it).
-    const int small_group = early_event ? 0 : dw_bf16_small_group();
+    const int small_group = ev ? 0 : dw_bf16_small_group();
     if (small_group) {
       static const int layers[6] = {1, 2, 3, 5, 6, 7};
       const unsigned char* Gs[6];
@@ -720,14 +749,14 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       for (int k = 0; k < 6; ++k) { Gs[k] = Gt(BG_L0 + layers[k]); Xs[k] = X(BS_H0 + layers[k] - 1); }
       HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st));
       for (int k = 0; k < 6; ++k)
-        red(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dw[2 * layers[k]], WIDTH, 0, dw[2 * layers[k] + 1]);
+        red(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dwp[2 * layers[k]], WIDTH, 0, dwp[2 * layers[k] + 1]);
       slabs += (size_t)6 * ns * 256 * 257;
       DwBfProd pr[4];
       memset(pr, 0, sizeof(pr));
       int n = 0, i_l4 = -1;
       if (small_group == 1) {
         HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
-        red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
+        red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dwp[8], WIDTH + POINT_DIM, 0, dwp[9]);
         slabs += (size_t)ns * 256 * 321;
       } else {
         i_l4 = n;
@@ -741,23 +770,23 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       pr[n++] = DwBfProd{Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, nullptr, 0};
       float* end = slabs;
       HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, slab_limit, &end, st));
-      if (i_l4 >= 0) red(pr[i_l4].slabs, pr[i_l4].nslab, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
-      red(pr[i_l0].slabs, pr[i_l0].nslab, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1]);
-      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR]);
-      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, 0, HALF, 32, WIDTH, at<float>(ws, L.mbuf), WIDTH, 0, nullptr);
-      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, HALF + 3, 1, 32, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr);
-      red(pr[i_c].slabs, pr[i_c].nslab, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR]);
-      red(pr[i_c].slabs, pr[i_c].nslab, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA]);
+      if (i_l4 >= 0) red(pr[i_l4].slabs, pr[i_l4].nslab, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dwp[8], WIDTH + POINT_DIM, 0, dwp[9]);
+      red(pr[i_l0].slabs, pr[i_l0].nslab, 256, 64, 0, 256, 0, POINT_DIM, dwp[0], POINT_DIM, 0, dwp[1]);
+      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, 0, HALF, 0, DIR_DIM, dwp[W_DIR], WIDTH + DIR_DIM, 0, dwp[B_DIR]);
+      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, 0, HALF, 32, WIDTH, mbuf, WIDTH, 0, nullptr);
+      red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, HALF + 3, 1, 32, WIDTH, dwp[W_SIGMA], WIDTH, 0, nullptr);
+      red(pr[i_c].slabs, pr[i_c].nslab, 32, 128, 0, 3, 0, HALF, dwp[W_COLOR], HALF, 0, dwp[B_COLOR]);
+      red(pr[i_c].slabs, pr[i_c].nslab, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dwp[B_SIGMA]);
       HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
       FoldGradArgs fg;
-      fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
-      fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
-      HIP_TRY(launch_fold_grads(fg, st));
+      fg.M = mbuf; fg.db_dir = dwp[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
+      fg.dW_pi = dwp[W_PI]; fg.db_pi = dwp[B_PI]; fg.dW_dir = dwp[W_DIR];
+      if (fold) HIP_TRY(launch_fold_grads(fg, st));
       return NERF_HIP_OK;
     }
     // layer 0: X = gamma_p
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
-    red(slabs, ns, 256, 64, 0, 256, 0, POINT_DIM, dw[0], POINT_DIM, 0, dw[1]);
+    red(slabs, ns, 256, 64, 0, 256, 0, POINT_DIM, dwp[0], POINT_DIM, 0, dwp[1]);
     slabs += (size_t)ns * 256 * 65;
     {  // layers 1, 2, 3, 5, 6, 7: six 256 x 256 products in ONE launch (42 workgroups each: a sixth of the slab traffic)
       static const int layers[6] = {1, 2, 3, 5, 6, 7};
@@ -766,36 +795,81 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       for (int k = 0; k < 6; ++k) { Gs[k] = Gt(BG_L0 + layers[k]); Xs[k] = X(BS_H0 + layers[k] - 1); }
       HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st));
       for (int k = 0; k < 6; ++k)
-        red(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dw[2 * layers[k]], WIDTH, 0, dw[2 * layers[k] + 1]);
+        red(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dwp[2 * layers[k]], WIDTH, 0, dwp[2 * layers[k] + 1]);
       slabs += (size_t)6 * ns * 256 * 257;
     }
     // layer 4: one pass over dpre4 for both column groups of the [256][316] matrix: X = [h3 | gamma_p]
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
-    red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dw[8], WIDTH + POINT_DIM, 0, dw[9]);
+    red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dwp[8], WIDTH + POINT_DIM, 0, dwp[9]);
     slabs += (size_t)ns * 256 * 321;
-    if (early_event) {  // point_layer[0..7] are complete here: their sums go out now, the rest of the products follow the event
+    if (ev) {  // point_layer[0..7] are complete here: their sums go out now, the rest of the products follow the event
       HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
-      HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(early_event), st));
+      HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev), st));
       rb.n = 0;
     }
     // point_info folded into dir_info (bf16_common.h): ONE product dpre_dir^T [gamma_d | h7] -- columns 0..23 are dir_info's direction
     // columns, columns 32.. are M = dpre_dir^T h7 (-> k_fold_grads below) -- and in the same pass over h7 the sigma head: row 3 of h7^T (dz, dspre)
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), wb_tot, slabs, &ns, st));
-    red(slabs, ns, 160, 288, 0, HALF, 0, DIR_DIM, dw[W_DIR], WIDTH + DIR_DIM, 0, dw[B_DIR]);
-    red(slabs, ns, 160, 288, 0, HALF, 32, WIDTH, at<float>(ws, L.mbuf), WIDTH, 0, nullptr);
-    red(slabs, ns, 160, 288, HALF + 3, 1, 32, WIDTH, dw[W_SIGMA], WIDTH, 0, nullptr);
+    red(slabs, ns, 160, 288, 0, HALF, 0, DIR_DIM, dwp[W_DIR], WIDTH + DIR_DIM, 0, dwp[B_DIR]);
+    red(slabs, ns, 160, 288, 0, HALF, 32, WIDTH, mbuf, WIDTH, 0, nullptr);
+    red(slabs, ns, 160, 288, HALF + 3, 1, 32, WIDTH, dwp[W_SIGMA], WIDTH, 0, nullptr);
     slabs += (size_t)ns * 160 * 289;
     // colour head = rows 0..2 of the (dz, dspre) tile against c; row 3 of its column sums = the sigma bias gradient
     HIP_TRY(launch_dw_bf16_gemm(Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
-    red(slabs, ns, 32, 128, 0, 3, 0, HALF, dw[W_COLOR], HALF, 0, dw[B_COLOR]);
-    red(slabs, ns, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dw[B_SIGMA]);
+    red(slabs, ns, 32, 128, 0, 3, 0, HALF, dwp[W_COLOR], HALF, 0, dwp[B_COLOR]);
+    red(slabs, ns, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dwp[B_SIGMA]);
     HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
     {
       FoldGradArgs fg;
-      fg.M = at<float>(ws, L.mbuf); fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
-      fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
-      HIP_TRY(launch_fold_grads(fg, st));
+      fg.M = mbuf; fg.db_dir = dwp[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
+      fg.dW_pi = dwp[W_PI]; fg.db_pi = dwp[B_PI]; fg.dW_dir = dwp[W_DIR];
+      if (fold) HIP_TRY(launch_fold_grads(fg, st));
     }
+    return NERF_HIP_OK;
+  };
+  if (bf16) {
+    ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
+    if (int rc = dw_bf16_phase(at<unsigned char>(ws, L.bsave), at<unsigned char>(ws, L.bG), dw, at<float>(ws, L.mbuf), early_event, true)) return rc;
+  } else if (split) {
+    // split-fp32 train step: G = G_hi + G_mid, X = X_hi + X_mid (bf16 parts, fragment layout): G^T X = G_hi^T X_hi + G_hi^T X_mid + G_mid^T X_hi
+    // + O(2^-16): three passes of the bf16 products into three gradient sets.  The column sums of G (every bias gradient) ride on each pass:
+    // pass 1 carries sum G_hi a second time, so the biases take passes 0 and 2 only.  k_fold_grads is linear in M and db_dir: once, on the sums.
+    ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
+    float* set1[24];
+    float* set2[24];
+    {
+      float* base = at<float>(ws, L.dwtmp);
+      size_t o = 0;
+      for (int t = 0; t < 24; ++t) {
+        set1[t] = base + o;
+        set2[t] = base + SPLIT_GRAD_SET_FLOATS + o;
+        o += ((size_t)param_numel(t) + 63) / 64 * 64;
+      }
+      if (o > (size_t)SPLIT_GRAD_SET_FLOATS) return fail(NERF_HIP_ERR_WORKSPACE, "split gradient scratch too small");
+    }
+    HIP_TRY(hipMemsetAsync(at<float>(ws, L.dwtmp), 0, (size_t)2 * SPLIT_GRAD_SET_FLOATS * sizeof(float), st));  // (tensors a pass does not write -- point_info's, dir_info's feature columns -- must not carry stale bits into the sum)
+    float* m0 = at<float>(ws, L.mbuf);
+    float* m1 = m0 + (size_t)HALF * WIDTH;
+    float* m2 = m1 + (size_t)HALF * WIDTH;
+    const unsigned char* xh = at<unsigned char>(ws, L.bsave);
+    const unsigned char* xm = at<unsigned char>(ws, L.bsave2);
+    const unsigned char* gh = at<unsigned char>(ws, L.bG);
+    const unsigned char* gm = at<unsigned char>(ws, L.bG2);
+    if (int rc = dw_bf16_phase(xh, gh, dw, m0, nullptr, false)) return rc;
+    if (int rc = dw_bf16_phase(xm, gh, set1, m1, nullptr, false)) return rc;
+    if (int rc = dw_bf16_phase(xh, gm, set2, m2, nullptr, false)) return rc;
+    SplitSumArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    for (int t = 0; t < 24; ++t) { sa.out[t] = dw[t]; sa.a[t] = set1[t]; sa.b[t] = set2[t]; sa.numel[t] = param_numel(t); }
+    sa.bias_mask = 0;
+    for (int t = 1; t < 24; t += 2) sa.bias_mask |= 1u << t;  // odd tensors = biases (weights24 order)
+    sa.m0 = m0; sa.m1 = m1; sa.m2 = m2; sa.m_numel = HALF * WIDTH;
+    HIP_TRY(launch_split_grad_sum(sa, st));
+    FoldGradArgs fg;
+    fg.M = m0; fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
+    fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
+    HIP_TRY(launch_fold_grads(fg, st));
+    if (early_event) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(early_event), st));  // (no early part in this mode: everything is final here)
   } else {
     ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
     DwBatch batch;
@@ -872,7 +946,7 @@ int nerf_hip_ws_offset(int B, int Nc, int Nf, int flags, const char* name, size_
   if (int rc = check_sizes(B, Nc, Nf)) return rc;
   const WsLayout L = layout(B, Nc, Nf, flags);
   struct { const char* n; size_t o; } tab[] = {
-      {"status", L.status}, {"dbg", L.dbg}, {"packed", L.packed}, {"packed_bf", L.packed_bf}, {"bsave", L.bsave}, {"bmask", L.bmask}, {"bG", L.bG}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
+      {"status", L.status}, {"dbg", L.dbg}, {"packed", L.packed}, {"packed_bf", L.packed_bf}, {"bsave", L.bsave}, {"bsave2", L.bsave2}, {"bmask", L.bmask}, {"bG", L.bG}, {"bG2", L.bG2}, {"rayf", L.rayf}, {"dvec", L.dvec}, {"t_c", L.t_c}, {"sig_c", L.sig_c},
       {"rgb_c", L.rgb_c}, {"w_c", L.w_c}, {"t_f", L.t_f}, {"sig_f", L.sig_f}, {"rgb_f", L.rgb_f}, {"perm", L.perm},
       {"w_m", L.w_m}, {"bundle", L.bundle}, {"save", L.save}, {"masks", L.masks}, {"spre", L.spre}, {"G", L.G}, {"dz", L.dz},
       {"dspre", L.dspre}, {"mbuf", L.mbuf}, {"fold", L.fold}, {"drgb_c", L.drgb_c}, {"dsig_c", L.dsig_c}, {"drgb_f", L.drgb_f}, {"dsig_f", L.dsig_f},

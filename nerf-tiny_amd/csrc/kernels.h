@@ -29,7 +29,8 @@ constexpr int FIELD_LDS_FLOATS = TM * LDA + 4 * TM * 3;
 struct FieldArgs {
   const float4* wp;        // packed weights (PACKED_FWD_F4 float4)
   const unsigned char* wbf;  // bf16 weight stream (bf16_common.h), bf16-MLP variant only
-  unsigned char* bsave;      // bf16 training: saved layer inputs in fragment layout (bf16_common.h)
+  unsigned char* bsave;      // bf16 training: saved layer inputs in fragment layout (bf16_common.h); split-fp32 training: their hi parts
+  unsigned char* bsave2;     // split-fp32 training: the mid parts, same layout
   uint16_t* bmask;           // bf16 training: ReLU alive masks
   int wb0, wb_tot;           // first wave block of this pass, wave blocks of both passes
   Weights24 w;             // raw parameter pointers (biases, sigma / colour heads)
@@ -150,8 +151,12 @@ hipError_t launch_render_pair_bf16x(const PairArgs& a, hipStream_t st);
 hipError_t launch_pack_weights_bf16x(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 // split-fp32 inference (field_fwd_split.hip): fp32 operands as two bf16 parts, three bf16 MFMAs per product
 size_t split_image_bytes();
+// split-fp32 training (field_bwd_split.hip): the transposed image of the backward chain, hi and mid fragment of every step interleaved
+size_t split_bwd_image_bytes();
+hipError_t launch_pack_weights_split_bwd(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
+constexpr int SPLIT_GRAD_SET_FLOATS = 600064;  // one set of the 24 gradient tensors, every tensor padded to 64 floats (>= 593,924 + 24 * 63)
 hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
-hipError_t launch_field_fwd_split(const FieldArgs& a, hipStream_t st);
+hipError_t launch_field_fwd_split(const FieldArgs& a, bool save, hipStream_t st);  // save: + hi / mid fragment-layout saves, masks, spre (FieldArgs bsave / bsave2 / bmask)
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
 // bf16 paths: fold + packed image(s) + ray records in ONE launch (prep_bf16.hip).  img_fwd: forward image (fwd_form 0: 32x32x16 stream,
 // 1: 16x16x32) or null = weights unchanged; img_bwd: transposed image of the backward chain or null; ready: PREP_READY_WORDS u32 words of the
@@ -190,6 +195,7 @@ struct FieldBwdArgs {
   const unsigned char* wbf;
   const uint16_t* bmask;
   unsigned char* bG;
+  unsigned char* bG2;      // split-fp32 training (field_bwd_split.hip): the gradients' mid parts (bG holds the hi parts), same layout
   int wb0, wb_tot;
   int row0, tile0, tiles_tot;
   long long Mtot;
@@ -297,6 +303,7 @@ struct SmallGradArgs {
 };
 
 hipError_t launch_field_bwd(const FieldBwdArgs& a, bool fine, hipStream_t st);
+hipError_t launch_field_bwd_split(const FieldBwdArgs& a, bool fine, hipStream_t st);  // split-fp32 training chain (field_bwd_split.hip)
 hipError_t launch_field_bwd_reg(const FieldBwdArgs& a, bool fine, hipStream_t st);
 hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st, const BwdFuse* fuse = nullptr);
 hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
@@ -359,6 +366,22 @@ struct GatherArgs {
 };
 
 hipError_t launch_adam(const AdamArgs& a, hipStream_t st);
+
+// split-fp32 train step: the three gradient sets of the hi x hi, hi x mid and mid x hi weight-gradient passes -> one (train_ops.hip).
+// out[t] += a[t] + b[t] for the weights, out[t] += b[t] for the biases (bit t of bias_mask: pass `a` = G_hi x X_mid carries the column sums of
+// G_hi a second time); m0 += m1 + m2 for the folded product's M.  Fixed order: deterministic.
+struct SplitSumArgs {
+  float* out[24];
+  const float* a[24];
+  const float* b[24];
+  int numel[24];
+  unsigned bias_mask;
+  float* m0;
+  const float* m1;
+  const float* m2;
+  int m_numel;
+};
+hipError_t launch_split_grad_sum(const SplitSumArgs& a, hipStream_t st);
 hipError_t launch_gather_rays(const GatherArgs& a, hipStream_t st);
 
 }  // namespace nerf

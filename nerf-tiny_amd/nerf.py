@@ -74,9 +74,12 @@ class ResampleIndexError(RuntimeError):
 
 def _call_flags(model, need_grad: bool) -> int:
     bf16 = getattr(model, "bf16_mlp", False)
+    # split-fp32: `split_mlp` selects it for inference calls; `split_train` (its own opt-in switch) for TRAINING calls -- forward, dX chain and
+    # weight-gradient products on bf16 MFMA with two-part operands (csrc/field_fwd_split.hip, field_bwd_split.hip, dw_bf16.hip x 3)
+    split = (getattr(model, "split_train", False) and not model.force_tile_kernel) if need_grad else getattr(model, "split_mlp", False)
     return ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
             | (_abi.BF16_MLP if bf16 else 0) | (_abi.CORRECTED if getattr(model, "corrected", False) else 0)
-            | (_abi.SPLIT_MLP if getattr(model, "split_mlp", False) and not need_grad and not bf16 else 0))  # inference only
+            | (_abi.SPLIT_MLP if split and not bf16 else 0))
 
 
 class _RenderFn(torch.autograd.Function):
@@ -171,6 +174,11 @@ class NeRFModel(nn.Module):
         #: and three MFMAs per product, fp32 accumulation -- inside the same 1e-4 bar as the exact-fp32 default,
         #: 3x faster.  Off by default: the default keeps exact k-ordered fp32 fma chains; training forwards ignore it
         self.split_mlp = False
+        #: TRAINING calls (a forward that records a graph, train_step): the whole train step in split-fp32 arithmetic -- every fp32 operand of
+        #: the forward, the dX chain and the weight-gradient products as two bf16 parts (hi + mid), three bf16 MFMAs per product, fp32
+        #: accumulation.  Opt-in, never the headline: the default keeps the exact fp32 kernels.  Loss to 1e-5 of the exact path's, gradients
+        #: inside the bands the exact path is held to against the reference (tests/test_gpu_split.py)
+        self.split_train = False
         #: OPTIONAL EXTRA, off by default, NOT the reference's results (SURVEY.md 8a "Q"): one stable sort of the merged samples by depth with
         #: rgb / sigma moving along (instead of nerf.py:307-308's five independent channel sorts) and a detached t_fine (instead of
         #: nerf.py:259's attached one).  Parity unpinned -- the reference has no such mode; tested against the oracle's restatement only
@@ -243,6 +251,7 @@ class NeRFModel(nn.Module):
         super().__setstate__(d)
         self.__dict__.setdefault("grad_bucket", None)
         self.__dict__.setdefault("split_mlp", False)
+        self.__dict__.setdefault("split_train", False)
         self.__dict__.setdefault("corrected", False)
         self.__dict__["_ws"], self.__dict__["_ws_generation"] = {}, {}
         self.__dict__["_last_ws"], self.__dict__["_packed"], self.__dict__["_frozen"] = None, set(), False

@@ -16,6 +16,7 @@ m = bench.synth_weights(0).to(dev)
 row, col, pb, Ct = row.to(dev), col.to(dev), pb.float().to(dev), Ct.to(dev)
 m.bf16_mlp = os.environ.get('BF16') == '1'
 m.split_mlp = os.environ.get('SPLIT') == '1'
+m.split_train = os.environ.get('SPLIT') == '1'  # (training calls: the split-fp32 train step, opt-in)
 train = os.environ.get('TRAIN') == '1'
 
 

@@ -53,11 +53,9 @@ def test_split_forward_ragged_and_maximum_sizes(oracle, pkg, dev, B, Nc, Nf):
     assert max_rel(Cc, oc) < TOL and max_rel(Cf, of) < TOL
 
 
-def test_split_is_inference_only_and_training_ignores_it(oracle, pkg, dev):
-    """a forward that records a graph runs the exact-fp32 training kernels whatever the flag says (bit-identical loss and gradients);
-    the C ABI refuses the combination outright"""
-    from nerf_tiny_amd import _abi
-
+def test_split_mlp_alone_leaves_training_exact(oracle, pkg, dev):
+    """`split_mlp` is the INFERENCE switch: a forward that records a graph runs the exact-fp32 training kernels whatever it says
+    (bit-identical loss and gradients); only `split_train` puts the train step on the split kernels."""
     g = load_golden("small_16_32")
     row, col, pb, K, Ct = golden_inputs(g)
     w, m = _model(pkg, oracle, g, dev, row.shape[0])
@@ -74,19 +72,113 @@ def test_split_is_inference_only_and_training_ignores_it(oracle, pkg, dev):
     m.split_mlp = True
     l1, g1 = step()
     assert l0 == l1 and all(torch.equal(a, b) for a, b in zip(g0, g1))
-    with pytest.raises(_abi.NerfHipError):
-        _abi.check(-1 if _abi.ws_bytes(8, 16, 32, _abi.SPLIT_MLP) <= 0 else _call_forward_with_save_and_split(pkg, m, row, col, pb, K, dev))
+    m.split_train = True
+    l2, g2 = step()
+    assert l2 != l0 and abs(l2 - l0) <= 1e-5 * abs(l0)  # other kernels, the same loss to 1e-5
 
 
-def _call_forward_with_save_and_split(pkg, m, row, col, pb, K, dev):
+def _decode_pieces(buf, wb_tot, ks_list, tensor, wb0, nwb):
+    """fragment layout (csrc/bf16_common.h) -> [nwb * 32 samples, 16 ks features] fp32: piece (wb, ks), lane (j, h), slot s holds feature
+    16 ks + 4 h + (s & 3) + 8 (s >> 2) of sample wb * 32 + j"""
+    ks_t = ks_list[tensor]
+    start = wb_tot * 1024 * sum(ks_list[:tensor])
+    raw = buf[start:start + wb_tot * ks_t * 1024].view(torch.bfloat16).view(wb_tot, ks_t, 2, 32, 8)[wb0:wb0 + nwb].float().cpu()
+    out = torch.zeros(nwb, 32, ks_t * 16)
+    for ks in range(ks_t):
+        for h in range(2):
+            for sl in range(8):
+                out[:, :, 16 * ks + 4 * h + (sl & 3) + 8 * (sl >> 2)] = raw[:, ks, h, :, sl]
+    return out.reshape(nwb * 32, ks_t * 16)
+
+
+BS_KS = [4] + [16] * 8 + [8, 2]       # gamma_p, h0..h7, c, gamma_d   (csrc/bf16_common.h)
+BG_KS = [16] * 8 + [8, 2]             # dpre0..7, dpre_dir, (dz, dspre)
+
+
+def _wave_blocks(B, N):
+    return ((B * N + 255) // 256) * 8
+
+
+@pytest.mark.parametrize("name,rays", [("cfg1_lego_crop32_sharp", 256), ("small_16_32", 50)])
+def test_split_training_forward_saves_hi_plus_mid(oracle, pkg, dev, name, rays):
+    """Stage 1 of the split-fp32 train step: the forward leaves every layer input as TWO bf16 fragment-layout tensors whose sum is the fp32
+    value to 2^-16 (hi = bf16(x), mid = bf16(x - hi)).  Compared on the COARSE pass (identical inputs in both runs) with the exact forward's fp32
+    rows: gamma_p / h0..h7 / c to 1e-4 of the tensor's size; the sigma pre-activation likewise; ragged row counts included (50 x 16 samples)."""
     from nerf_tiny_amd import _abi
 
-    B, Nc, Nf = row.shape[0], m.num_coarse, m.num_fine
-    flags = _abi.SAVE_FOR_BACKWARD | _abi.SPLIT_MLP
-    ws = torch.empty(_abi.ws_bytes(B, Nc, Nf, flags), dtype=torch.uint8, device=dev)
-    ps = list(m.network.parameters())
-    Cc, Cf = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
-    K9 = _abi.f32_array(K.reshape(-1).tolist())
-    return _abi.lib().nerf_hip_forward(_abi.ptr_array(ps), row.to(dev).data_ptr(), col.to(dev).data_ptr(), pb.float().to(dev).data_ptr(), K9, None,
-                                       B, Nc, Nf, 1e-4, Cc.data_ptr(), Cf.data_ptr(), ws.data_ptr(), ws.numel(), flags,
-                                       torch.cuda.current_stream(dev).cuda_stream)
+    g = load_golden(name)
+    row, col, pb, K, Ct = (x[:rays] if (torch.is_tensor(x) and x.dim() > 0 and x.shape[0] > 3) else x for x in golden_inputs(g))
+    Nc, Nf = int(g["Nc"]), int(g["Nf"])
+    M, Mc = rays * (Nc + Nf), rays * Nc
+    w, m = _model(pkg, oracle, g, dev, rays)
+    Cc0, Cf0 = m(row, col, pb, K)
+    f0 = _abi.SAVE_FOR_BACKWARD
+    save = _abi.ws_view(m.last_workspace, rays, Nc, Nf, f0, "save", (10, M + 64, 256)).clone().cpu()
+    spre0 = _abi.ws_view(m.last_workspace, rays, Nc, Nf, f0, "spre", (M,)).clone().cpu()
+    m.split_train = True
+    Cc1, Cf1 = m(row, col, pb, K)
+    f1 = _abi.SAVE_FOR_BACKWARD | _abi.SPLIT_MLP
+    wb_c, wb_tot = _wave_blocks(rays, Nc), _wave_blocks(rays, Nc) + _wave_blocks(rays, Nf)
+    nbytes = wb_tot * sum(BS_KS) * 1024
+    hi = _abi.ws_view(m.last_workspace, rays, Nc, Nf, f1, "bsave", (nbytes,), torch.uint8)
+    mid = _abi.ws_view(m.last_workspace, rays, Nc, Nf, f1, "bsave2", (nbytes,), torch.uint8)
+    spre1 = _abi.ws_view(m.last_workspace, rays, Nc, Nf, f1, "spre", (M,)).clone().cpu()
+    assert max_rel(Cc1, Cc0) < 2e-5 and max_rel(Cf1, Cf0) < TOL
+    nwb = (Mc + 31) // 32
+    # (tensor index in the fragment buffers, tensor index in the fp32 row buffer, columns)
+    for tb, tf, cols in [(0, 9, 60)] + [(1 + l, l, 256) for l in range(8)] + [(9, 8, 128)]:
+        got = (_decode_pieces(hi, wb_tot, BS_KS, tb, 0, nwb) + _decode_pieces(mid, wb_tot, BS_KS, tb, 0, nwb))[:Mc, :cols]
+        ref = save[tf, :Mc, :cols]
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= (3e-5 if tb == 0 else 1e-4) * scale + 1e-7, (tb, err, scale)
+    assert float((spre1[:Mc] - spre0[:Mc]).abs().max()) <= 1e-4 * float(spre0[:Mc].abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("name", ["cfg1_lego_crop32", "cfg1_lego_crop32_sharp", "cfg4_fern_rand512", "small_16_32", "cfg2_lego_rand4096"])
+def test_split_train_step_end_to_end(oracle, pkg, dev, name):
+    """VERDICT round 4 item 8 (stretch, opt-in): the whole train step in split-fp32 arithmetic (model.split_train).  Loss to 1e-5 of the
+    reference's; every gradient tensor against the oracle inside the band the exact path is held to -- twice the oracle's OWN shift under a
+    seeded relative weight perturbation (floor 1e-3) -- with the perturbation at the mode's accuracy class (1e-5 instead of 1e-6: its products
+    carry 16 significant bits); and close to the exact device path's own gradients."""
+    from test_gpu_backward import _oracle_grads, _sensitivity_band
+
+    from conftest import l2_rel
+
+    g = load_golden(name)
+    inputs = golden_inputs(g)
+    row, col, pb, K, Ct = inputs
+    Nc, Nf = int(g["Nc"]), int(g["Nf"])
+    w, m = _model(pkg, oracle, g, dev, row.shape[0])
+    Cc, Cf, loss0 = m.train_step(row, col, pb, K, Ct)
+    exact = [p.grad.clone() for p in m.network.parameters()]
+    m.split_train = True
+    Cc, Cf, loss = m.train_step(row, col, pb, K, Ct)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert max_rel(Cc, g["C_coarse"]) < TOL and max_rel(Cf, g["C_fine"]) < TOL
+    _, g0 = _oracle_grads(oracle, w, inputs, Nc, Nf)
+    band = _sensitivity_band(oracle, w, inputs, Nc, Nf, g0, seeds=(1,) if name.startswith("cfg2") else (1, 2), rel=1e-5)
+    worst = (0.0, 1.0, "")
+    rows = []
+    for (k, q), ex in zip(m.named_parameters(), exact):
+        key = k if k.startswith("network.") else "network." + k
+        assert torch.isfinite(q.grad).all(), k
+        e = l2_rel(q.grad, g0[key])
+        bar = max(2.0 * band[key], 1e-3)
+        rows.append((k, e, bar, l2_rel(q.grad, ex)))
+        if e / bar > worst[0] / worst[1]:
+            worst = (e, bar, k)
+    for k, e, bar, ex in rows:
+        print(f"  {k:34s} vs oracle {e:.2e} (bar {bar:.2e})   vs the exact device path {ex:.2e}")
+    for k, e, bar, ex in rows:
+        assert e < bar, (k, e, bar)
+    print(f"{name}: split-fp32 train step: closest to its bar: {worst[2]} L2-rel {worst[0]:.2e} (bar {worst[1]:.2e})")
+    # the autograd surface takes the same path: identical loss and gradients
+    grads = [p.grad.clone() for p in m.network.parameters()]
+    for p in m.network.parameters():
+        p.grad = None
+    Cc2, Cf2 = m(row, col, pb, K)
+    l2 = m.ray_loss(Cc2, Cf2, Ct.to(dev))
+    l2.backward()
+    assert float(l2.detach()) == float(loss)
+    assert all(torch.equal(a, p.grad) for a, p in zip(grads, m.network.parameters()))
