@@ -213,10 +213,13 @@ PMC_FILES = {(False, False): "pmc_latest.json", (True, False): "pmc_train_latest
 
 
 PMC_SPLIT_FILE = "pmc_split_fwd_latest.json"
+PMC_SPLIT_TRAIN_FILE = "pmc_split_train_latest.json"
 
 
 def pmc_file(leg):
-    return PMC_SPLIT_FILE if getattr(leg, "split", False) else PMC_FILES[(leg.train, leg.bf16)]
+    if getattr(leg, "split", False):
+        return PMC_SPLIT_TRAIN_FILE if leg.train else PMC_SPLIT_FILE
+    return PMC_FILES[(leg.train, leg.bf16)]
 
 
 def read_traffic(leg, kernel_keys, scale=None):
@@ -255,7 +258,8 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket, time_allred
 
     row, col, pb, C_true = inputs
     model.bf16_mlp = leg.bf16
-    model.split_mlp = leg.split
+    model.split_mlp = leg.split and not leg.train
+    model.split_train = leg.split and leg.train  # opt-in: the whole train step in split-fp32 arithmetic
     model.grad_bucket = bucket if leg.train else None
     ar_events = []
 
@@ -320,7 +324,7 @@ def run_leg(leg, model, inputs, K, steps, warmup, dist, dev, bucket, time_allred
         elapsed = float(t.item())
     ar_ms = (sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)) if ar_events else None
     model.grad_bucket = None
-    model.split_mlp = False
+    model.split_mlp = model.split_train = False
     return elapsed, prof, ar_ms
 
 
@@ -352,8 +356,8 @@ def rooflines(leg, prof, b_local, steps):
     # EXECUTE -- 8/9 of the reference network's 1,182,976 per sample: point_info is folded into dir_info (one 128 x 256
     # layer instead of 256 x 256 + 128 x 256) -- so `frac` is a hardware fraction (<= 1); the reference graph's
     # FLOPs over the same time are `achieved_algorithmic` / `frac_algorithmic`.
-    if getattr(leg, "split", False):
-        # split-fp32 inference: the fp32 MLP on the bf16 pipe, THREE bf16 MFMAs (hi*hi, hi*mid, mid*hi) per fp32 product.  Roofline = the
+    def split_block():
+        # split-fp32 forward: the fp32 MLP on the bf16 pipe, THREE bf16 MFMAs (hi*hi, hi*mid, mid*hi) per fp32 product.  Roofline = the
         # bf16 MFMA peak against the bf16 FLOPs the kernel executes (3 x the executed fp32 ones); the algorithmic fp32 figure beside it
         ms = sum(prof.get(k, (0.0, 0))[0] for k in ("field_fwd_coarse", "field_fwd_fine"))
         n = sum(prof.get(k, (0.0, 0))[1] for k in ("field_fwd_coarse", "field_fwd_fine"))
@@ -361,15 +365,17 @@ def rooflines(leg, prof, b_local, steps):
         alg = FLOP_PER_SAMPLE * b_local * (NC + NF) // 2
         exe = 3 * EXEC_FLOP_PER_SAMPLE * b_local * (NC + NF) // 2
         ach = exe / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
-        blk = {"bound": "mfma (bf16 pipe)", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
-               "traffic": scaled(read_traffic(leg, ["k_field_fwd_split"])), "traffic_source": src,
-               "kernel": "k_field_fwd_split (average of the coarse- and fine-pass launches)", "avg_launch_ms": round(avg, 4), "launches": n,
-               "flop_per_launch": exe, "achieved_algorithmic_fp32": round(alg / (avg * 1e-3) / 1e12, 2) if avg > 0 else 0.0,
-               "algorithmic_over_fp32_mfma_peak": round(alg / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3) if avg > 0 else 0.0,
-               "note": "achieved = executed bf16 MFMA FLOPs (3 per fp32 product of the folded network) against the dense bf16 peak; "
-                       "achieved_algorithmic_fp32 = the reference network's fp32 FLOPs (SURVEY.md 8d) per second, above the fp32 MFMA peak because "
-                       "the products run on the bf16 pipe with 16-bit-mantissa operands (parity: `parity.split_mlp_vs_reference`)"}
-        return blk, None
+        return {"bound": "mfma (bf16 pipe)", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                "traffic": None if leg.train else scaled(read_traffic(leg, ["k_field_fwd_split"])), "traffic_source": src,
+                "kernel": "k_field_fwd_split" + ("<SAVE>" if leg.train else "") + " (average of the coarse- and fine-pass launches)", "avg_launch_ms": round(avg, 4), "launches": n,
+                "flop_per_launch": exe, "achieved_algorithmic_fp32": round(alg / (avg * 1e-3) / 1e12, 2) if avg > 0 else 0.0,
+                "algorithmic_over_fp32_mfma_peak": round(alg / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3) if avg > 0 else 0.0,
+                "note": "achieved = executed bf16 MFMA FLOPs (3 per fp32 product of the folded network) against the dense bf16 peak; "
+                        "achieved_algorithmic_fp32 = the reference network's fp32 FLOPs (SURVEY.md 8d) per second, above the fp32 MFMA peak because "
+                        "the products run on the bf16 pipe with 16-bit-mantissa operands (parity: `parity.split_mlp_vs_reference`)"}
+
+    if getattr(leg, "split", False) and not leg.train:
+        return split_block(), None
     fwd_kernel = ("k_field_fwd_bf16<SAVE>" if leg.train else "k_field_fwd_bf16x") if leg.bf16 else ("k_field_fwd_reg<SAVE>" if leg.train else "k_field_fwd_reg")
     fwd_key = (["k_field_fwd_bf16<true, 8>"] if leg.train else ["k_field_fwd_bf16x<2, 8>"]) if leg.bf16 else (["k_field_fwd_reg<true, false>"] if leg.train else ["k_field_fwd"])
     if "render_pair" in prof:  # small bf16-MLP inference batches: ONE launch holds both field passes and both composites of every ray pair
@@ -379,7 +385,37 @@ def rooflines(leg, prof, b_local, steps):
     else:
         fwd = mfma(fwd_kernel + " (average of the coarse- and fine-pass launches)", ("field_fwd_coarse", "field_fwd_fine"),
                    FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)
-    fwd["note"] = ("achieved / frac count the FLOPs the kernel EXECUTES (8/9 of the reference network's: point_info folded into dir_info, "
+    if getattr(leg, "split", False) and leg.train:
+        # the opt-in split-fp32 TRAIN step: forward (field_fwd_split<SAVE>), dX chain (field_bwd_split) on the bf16 pipe with THREE bf16 MFMAs per fp32
+        # product -- executed bf16 FLOPs against the dense bf16 peak -- and the weight gradients as three passes of the bf16 products (hi x hi,
+        # hi x mid, mid x hi): HBM-bound like the bf16 variant's, three times its operand bytes
+        fwd = split_block()
+        fwd["traffic"] = scaled(read_traffic(leg, ["k_field_fwd_split<true>"]))
+        cms = sum(prof.get(k, (0.0, 0))[0] for k in ("bwd_field_fine", "bwd_field_coarse"))
+        cn = sum(prof.get(k, (0.0, 0))[1] for k in ("bwd_field_fine", "bwd_field_coarse"))
+        cavg = cms / max(cn, 1)
+        chain_exec_ = 1.0 - 2 * 65536 * (NC + NF) / (CHAIN_FLOP_COARSE * NC + CHAIN_FLOP_FINE * NF)
+        calg = (CHAIN_FLOP_COARSE * b_local * NC + CHAIN_FLOP_FINE * b_local * NF) // 2
+        cexe = int(3 * calg * chain_exec_)
+        cach = cexe / (cavg * 1e-3) / 1e12 if cavg > 0 else 0.0
+        chain = {"bound": "mfma (bf16 pipe)", "achieved": round(cach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(cach / PEAK_BF16_MFMA_TFLOPS, 4),
+                 "traffic": scaled(read_traffic(leg, ["k_field_bwd_split<true>", "k_field_bwd_split<false>"])), "traffic_source": src,
+                 "kernel": "k_field_bwd_split (dX chain, two-part operands; average of the fine- and coarse-pass launches)", "avg_launch_ms": round(cavg, 4), "launches": cn,
+                 "flop_per_launch": cexe, "achieved_algorithmic_fp32": round(calg / (cavg * 1e-3) / 1e12, 2) if cavg > 0 else 0.0}
+        dw_ms = prof.get("bwd_dw", (0.0, 0))[0] / max(prof.get("bwd_dw", (0.0, 1))[1], 1)
+        wb = ((b_local * NC + 255) // 256 + (b_local * NF + 255) // 256) * 8
+        dw_bytes = 3 * DW_BF16_KIB_PER_WAVE_BLOCK * 1024 * wb
+        dw = {"bound": "hbm", "achieved": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1) if dw_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "frac": round(dw_bytes / (dw_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if dw_ms > 0 else 0.0, "traffic": None, "traffic_source": src,
+              "kernel": "k_dw_bf16 x 3 (hi x hi, hi x mid, mid x hi passes of the weight-gradient products + reduces + the sum of the three sets)",
+              "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "bytes_per_launch": dw_bytes}
+        for blk in (fwd, chain):
+            if blk.get("traffic") and blk["avg_launch_ms"] > 0:
+                blk["hbm_gbs"] = round(blk["traffic"] / (blk["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                blk["hbm_frac"] = round(blk["hbm_gbs"] / PEAK_HBM_GBS, 4)
+        phases = {"forward_with_saves": fwd, "dx_chain": chain, "dw": dw}
+        return max(phases.values(), key=lambda b: b["avg_launch_ms"] * (2 if b is not dw else 1)), phases
+    fwd["note"] = fwd.get("note") or ("achieved / frac count the FLOPs the kernel EXECUTES (8/9 of the reference network's: point_info folded into dir_info, "
                    "DESIGN.md 3a) -- the MFMA pipe's side, the figure the MFMA-busy counter corroborates; achieved_algorithmic / frac_algorithmic "
                    "price the reference graph's FLOPs (SURVEY.md 8d) over the same time")
     if not leg.train:
@@ -481,7 +517,8 @@ def leg_report(leg, elapsed, prof, ar_ms, steps, warmup, world, b_local, strong)
     roof, phases = rooflines(leg, prof, b_local, steps)
     rep = {"metric": "rays/sec (64 coarse + 128 fine samples), lego 400x400" + (" [train step: fwd+loss+bwd]" if leg.train else "")
                      + (" [cfg3: bf16 MLP / fp32 composite]" if leg.bf16 else "")
-                     + (" [split-fp32 inference: fp32 operands as bf16 hi + mid, 3 bf16 MFMAs per product, fp32 accumulate; same 1e-4 bar]" if getattr(leg, "split", False) else ""),
+                     + (" [split-fp32 inference: fp32 operands as bf16 hi + mid, 3 bf16 MFMAs per product, fp32 accumulate; same 1e-4 bar]" if getattr(leg, "split", False) and not leg.train else "")
+                     + (" [opt-in split-fp32 train step: forward, dX chain and weight gradients with fp32 operands as bf16 hi + mid, 3 bf16 MFMAs per product, fp32 accumulate]" if getattr(leg, "split", False) and leg.train else ""),
            "value": round(value, 1), "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
            "dtype": "bf16" if leg.bf16 else ("f32 (bf16 hi+mid split operands, fp32 accumulate)" if getattr(leg, "split", False) else "f32"), "roofline": roof,
            "whole_path_tflops_per_gpu": round(value / world * flop_ray / 1e12, 2),
@@ -605,7 +642,7 @@ def compact_line(full, side_path=None):
     if "allreduce_ms" in full:
         line["allreduce_ms"] = full["allreduce_ms"]
     ex = full.get("extra", {})
-    for name in ("train_f32", "forward_bf16", "train_bf16", "forward_f32_split"):
+    for name in ("train_f32", "forward_bf16", "train_bf16", "forward_f32_split", "train_f32_split"):
         if name in ex:
             line[name + "_rays_per_s"] = ex[name].get("value")
     for name in ("train_f32", "train_bf16"):  # the N > 1 strong-scaling legs: one 4096-ray batch split over the ranks
@@ -771,15 +808,15 @@ def main():
         b_local = B // world
     inputs = shard(full, rank * b_local, (rank + 1) * b_local) if strong else shard(full, 0, B)
 
-    if args.split and (args.mode == "train" or args.mlp == "bf16"):
-        raise SystemExit("--split is the fp32 inference mode: not with --mode train / --mlp bf16")
+    if args.split and args.mlp == "bf16":
+        raise SystemExit("--split is the split-fp32 mode (inference: model.split_mlp, train step: model.split_train): not with --mlp bf16")
     head = Leg("headline", args.mode == "train", args.mlp == "bf16", args.split)
     elapsed, prof, ar_ms = run_leg(head, model, inputs, K, args.steps, args.warmup, dist, dev, bucket)
     rep = leg_report(head, elapsed, prof, ar_ms, args.steps, args.warmup, world, b_local, strong)
     extra = {}
     # (name, train, bf16, timed steps, warm-up steps): every leg is timed over >= 0.1 s
     legs = (("forward_f32", False, False, 20, 3), ("train_f32", True, False, 8, 2), ("forward_bf16", False, True, 160, 8), ("train_bf16", True, True, 40, 4),
-            ("forward_f32_split", False, False, 60, 4))
+            ("forward_f32_split", False, False, 60, 4), ("train_f32_split", True, False, 8, 2))
     def brief(r, rays_per_step):
         return {k: r[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_with_kernel_events", "steps", "dtype", "kernel_ms_per_step", "allreduce_ms") if k in r} | {
             "rays_per_step": rays_per_step, "roofline_frac": r["roofline"]["frac"], "roofline_frac_algorithmic": r["roofline"].get("frac_algorithmic"),

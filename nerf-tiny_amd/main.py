@@ -33,6 +33,8 @@ if __name__ == "__main__":
     ap.add_argument("--bf16-mlp", action="store_true", help="run the MLP on bf16 MFMA (cfg3; also ini key BF16_MLP = True)")
     ap.add_argument("--on-resample-fault", choices=["raise", "warn", "ignore"], default=None,
                     help="what to do when a forward met the reference's exit(0) condition (nerf.py:251-253); default raise, like the reference stops")
+    ap.add_argument("--split-train", action="store_true", help="train in split-fp32 arithmetic (forward, dX chain and weight gradients on bf16 MFMA with "
+                                                               "two-part operands): 2x the exact fp32 step, opt-in (also ini key SPLIT_TRAIN = True)")
     ap.add_argument("--split-mlp", action="store_true", help="render (validation, display) on the split-fp32 inference kernels: same 1e-4 bar, "
                                                              "3x the rate; training is unaffected (also ini key SPLIT_MLP = True)")
     args = ap.parse_args()
@@ -49,6 +51,7 @@ if __name__ == "__main__":
         kw["datasets"] = {"train": scene, "val": scene, "test": scene}
     kw["bf16_mlp"] = args.bf16_mlp or ast.literal_eval(c("BF16_MLP", "False"))
     kw["split_mlp"] = args.split_mlp or ast.literal_eval(c("SPLIT_MLP", "False"))
+    kw["split_train"] = args.split_train or ast.literal_eval(c("SPLIT_TRAIN", "False"))
     if args.on_resample_fault or c("ON_RESAMPLE_FAULT"):
         kw["on_resample_fault"] = args.on_resample_fault or c("ON_RESAMPLE_FAULT")
     # data-parallel: started as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 .../main.py ...`

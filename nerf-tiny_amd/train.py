@@ -116,7 +116,9 @@ class NeRFRunner:
     and ``display()`` (nerf.py:503).  ``mode`` defaults to "train" so the reference's ``main.py:55`` call works.
     Extra keyword-only arguments: ``datasets`` (dict mode -> dataset, to run without files), ``log_every`` (host sync
     period; the reference syncs every iteration), ``bf16_mlp`` (BASELINE.json cfg3: the MLP on bf16 MFMA, default off), ``split_mlp`` (rendering calls -- validation,
-    ``display()`` -- on the split-fp32 inference kernels: same 1e-4 bar, 3x the rate; training forwards ignore it; default off),
+    ``display()`` -- on the split-fp32 inference kernels: same 1e-4 bar, 3x the rate; training forwards ignore it; default off), ``split_train`` (the TRAIN
+    step in split-fp32 arithmetic -- forward, dX chain and weight-gradient products on bf16 MFMA with two-part operands: 2x the exact fp32 step, gradients
+    inside the bands the exact path is held to; default off, ignored with ``bf16_mlp``),
     ``on_resample_fault`` ("raise" | "warn" | "ignore": what to do when ANY iteration since the last logging point met the reference's
     exit(0) condition of nerf.py:251-253 -- a training run that has died; the kernels record it in a sticky status word, the device path
     itself clamps the index and goes on.  Default "raise": the reference stops there too), ``distributed`` (None: data-parallel iff a
@@ -137,7 +139,7 @@ class NeRFRunner:
     def __init__(self, gpu=0, img_dir="../nerf_synthetic/lego/", results_path="./results/", ckpt_path="./checkpoint/", low_res=1,
                  total_iter=100000, batch_ray=400, learning=1e-3, lr_gamma=0.1, lr_milestone=(10, 200), n_coarse=64, n_fine=128,
                  data_type="sync", step=100, decay_end=200000, sched="EXP", continue_=False, *, datasets=None, log_every=None,
-                 seed=624, bf16_mlp=False, split_mlp=False, on_resample_fault="raise", distributed=None, overlap_allreduce=None):
+                 seed=624, bf16_mlp=False, split_mlp=False, split_train=False, on_resample_fault="raise", distributed=None, overlap_allreduce=None):
         from . import nerf as _nerf
         from . import parallel as par
 
@@ -200,6 +202,7 @@ class NeRFRunner:
         self.last_iter = last_iter
         self.model.bf16_mlp = bool(bf16_mlp)  # an attribute, not part of the checkpoint format: set after a resume too
         self.model.split_mlp = bool(split_mlp)
+        self.model.split_train = bool(split_train)  # opt-in: the train step in split-fp32 arithmetic (2x the exact step's rate)
         # the gradients of every step live in ONE flat buffer whose views are p.grad (the kernels write straight into it: no 24 fresh
         # tensors per iteration) -- the all-reduce buffer of a data-parallel run
         self.bucket = par.GradBucket(self.model.network.parameters())

@@ -11,7 +11,7 @@ cd $ROOT
 echo "[collect] bench default line"
 python3 bench.py --side-file $OUT/bench_extra.json > $OUT/bench_default.json 2> $OUT/bench_default.err && echo "bench (default line) done: $(wc -c < $OUT/bench_default.json) bytes"
 cd /tmp && export TMPDIR=/tmp
-for leg in "fwd_f32:--mode forward --mlp f32 --steps 20 --warmup 3" "train_f32:--mode train --mlp f32 --steps 6 --warmup 2" "fwd_bf16:--mode forward --mlp bf16 --steps 40 --warmup 5" "train_bf16:--mode train --mlp bf16 --steps 10 --warmup 3" "split_fwd:--mode forward --split --steps 30 --warmup 4"; do
+for leg in "fwd_f32:--mode forward --mlp f32 --steps 20 --warmup 3" "train_f32:--mode train --mlp f32 --steps 6 --warmup 2" "fwd_bf16:--mode forward --mlp bf16 --steps 40 --warmup 5" "train_bf16:--mode train --mlp bf16 --steps 10 --warmup 3" "split_fwd:--mode forward --split --steps 30 --warmup 4" "train_split:--mode train --split --steps 10 --warmup 3"; do
   name=${leg%%:*}; args=${leg#*:}
   echo "[collect] $name: kernel stats"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $name -- python3 $ROOT/bench.py $args --no-cpu-baseline --no-extra --side-file $OUT/${name}_extra.json > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_rocprof.err && echo "rocprof stats $name done"

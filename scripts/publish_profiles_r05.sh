@@ -6,7 +6,7 @@ TAG=${1:-r05}
 SRC=$ROOT/gpurun_out/$TAG
 cp $SRC/bench_default.json $ROOT/profiles/r05_bench_default.json
 cp $SRC/bench_extra.json $ROOT/profiles/r05_bench_extra.json
-for leg in fwd_f32 train_f32 fwd_bf16 train_bf16 split_fwd; do
+for leg in fwd_f32 train_f32 fwd_bf16 train_bf16 split_fwd train_split; do
   cp $SRC/${leg}_kernel_stats.csv $ROOT/profiles/r05_${leg}_kernel_stats.csv
   cp $SRC/${leg}_under_rocprof.json $ROOT/profiles/r05_${leg}_bench_under_rocprof.json
   python3 $ROOT/scripts/summarize_pmc.py r05 $leg > /dev/null

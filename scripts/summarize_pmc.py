@@ -30,7 +30,7 @@ p = os.path.join(root, "profiles", f"{tag}_{mode}_pmc.json")
 json.dump(out, open(p, "w"), indent=1, sort_keys=True)
 # the summaries bench.py reads for `roofline.traffic` (one per leg)
 latest = {"forward": "pmc_latest.json", "fwd_f32": "pmc_latest.json", "train_f32": "pmc_train_latest.json",
-          "fwd_bf16": "pmc_bf16_fwd_latest.json", "train_bf16": "pmc_bf16_train_latest.json", "split_fwd": "pmc_split_fwd_latest.json"}
+          "fwd_bf16": "pmc_bf16_fwd_latest.json", "train_bf16": "pmc_bf16_train_latest.json", "split_fwd": "pmc_split_fwd_latest.json", "train_split": "pmc_split_train_latest.json"}
 if mode in latest:
     json.dump(out, open(os.path.join(root, "profiles", latest[mode]), "w"), indent=1, sort_keys=True)
 for k in sorted(out):

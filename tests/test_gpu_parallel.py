@@ -63,8 +63,8 @@ def test_bench_train_leg_with_rccl_allreduce(tmp_path):
     assert out["allreduce_ms"] is not None and 0.0 < out["allreduce_ms"] < 50.0
     assert set(out["roofline_phases"]) == {"forward_with_saves", "dx_chain", "dw"}
     # the weak legs and -- the code path of the driver's N = 8 line -- the strong-scaling form of all four legs (here: one rank = the whole batch)
-    assert set(out["extra"]) == {"forward_f32", "forward_bf16", "train_bf16", "forward_f32_split", "strong_forward_f32", "strong_train_f32", "strong_forward_bf16",
-                                 "strong_train_bf16", "strong_forward_f32_split"}
+    assert set(out["extra"]) == {"forward_f32", "forward_bf16", "train_bf16", "forward_f32_split", "train_f32_split", "strong_forward_f32", "strong_train_f32",
+                                 "strong_forward_bf16", "strong_train_bf16", "strong_forward_f32_split", "strong_train_f32_split"}
     for name, leg in out["extra"].items():
         if name.startswith("strong_"):
             # `roofline.frac` is a HARDWARE fraction (executed FLOPs or measured bytes over the peak): never above 1
@@ -93,7 +93,7 @@ def test_bench_default_line_carries_the_per_rank_proxy(tmp_path):
     assert line["train_f32_rays_per_s"] == out["extra"]["train_f32"]["value"] and line["train_bf16_rays_per_s"] == out["extra"]["train_bf16"]["value"]
     px = out["per_rank_proxy"]
     for bs in ("512", "400"):
-        assert set(px[bs]) == {"forward_f32", "train_f32", "forward_bf16", "train_bf16", "forward_f32_split"}
+        assert set(px[bs]) == {"forward_f32", "train_f32", "forward_bf16", "train_bf16", "forward_f32_split", "train_f32_split"}
         for name, leg in px[bs].items():
             assert leg["rays_per_step"] == int(bs) and leg["ms_per_step"] > 0 and 0.0 < leg["roofline_frac"] <= 1.0
             if name.startswith("train"):

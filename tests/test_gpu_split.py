@@ -157,7 +157,9 @@ def test_split_train_step_end_to_end(oracle, pkg, dev, name):
     assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     assert max_rel(Cc, g["C_coarse"]) < TOL and max_rel(Cf, g["C_fine"]) < TOL
     _, g0 = _oracle_grads(oracle, w, inputs, Nc, Nf)
-    band = _sensitivity_band(oracle, w, inputs, Nc, Nf, g0, seeds=(1,) if name.startswith("cfg2") else (1, 2), rel=1e-5)
+    # three seeds where the oracle is cheap: the reference's gradient is piecewise -- on small_16_32 ONE discrete decision moves
+    # layer 0's weight gradient by 74 % and flips under one seeded 1e-6 jitter out of three; two evaluations of the same weights may land on either side
+    band = _sensitivity_band(oracle, w, inputs, Nc, Nf, g0, seeds=(1,) if name.startswith("cfg2") else (1, 2, 3), rel=1e-5)
     worst = (0.0, 1.0, "")
     rows = []
     for (k, q), ex in zip(m.named_parameters(), exact):
