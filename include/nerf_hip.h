@@ -67,11 +67,14 @@ enum {
   NERF_HIP_WEIGHTS_UNCHANGED = 1 << 3, /* nerf_hip_forward only: the caller guarantees that weights24 hold the same values as in the
                                           previous nerf_hip_forward call on this workspace with the same other flags, so the
                                           packed weight image in the workspace is reused instead of rebuilt (rendering loops) */
-  NERF_HIP_SPLIT_MLP = 1 << 4,         /* nerf_hip_forward WITHOUT NERF_HIP_SAVE_FOR_BACKWARD only (inference): the linear layers run on bf16 MFMA
-                                          with every fp32 operand split into two bf16 parts (hi + mid, 16 significant bits) and three
-                                          MFMAs per product, fp32 accumulation -- within the same 1e-4 bar as the exact-fp32 default
-                                          (measured 3e-6 / 2e-5 against the reference's outputs), several times faster; opt-in because
-                                          the default keeps exact k-ordered fp32 fma chains.  Ignored with NERF_HIP_BF16_MLP */
+  NERF_HIP_SPLIT_MLP = 1 << 4,         /* OPT-IN split-fp32 arithmetic: the linear layers run on bf16 MFMA with every fp32 operand split into two
+                                          bf16 parts (hi + mid, 16 significant bits) and three MFMAs per product, fp32 accumulation.
+                                          Without NERF_HIP_SAVE_FOR_BACKWARD (inference): within the same 1e-4 bar as the exact-fp32 default
+                                          (measured 3e-6 / 2e-5 against the reference's outputs), 3x its rate.  WITH it (the split-fp32 TRAIN
+                                          step; pass the flag to nerf_hip_backward / nerf_hip_train_step as well): forward, dX chain and
+                                          weight-gradient products in that arithmetic, 2x the exact step's rate, loss to 1e-5, gradients inside
+                                          the bands the exact path is held to.  Off by default: the default keeps exact k-ordered fp32 fma
+                                          chains.  Ignored with NERF_HIP_BF16_MLP */
   NERF_HIP_CORRECTED = 1 << 5,         /* OPTIONAL EXTRA, off by default, NOT the reference's results (SURVEY.md 8a "Q": reproduce the quirks by
                                           default, offer a flagged corrected mode): (Q1) the merged samples are sorted ONCE, by depth, stably, and
                                           rgb / sigma move with their sample, instead of nerf.py:307-308's five independent channel sorts; (Q9) t_fine
