@@ -187,6 +187,22 @@ def test_data_parallel_runner_single_rank_rccl_equals_plain_runner(tmp_path, bf1
 
 
 @pytest.mark.timeout(900)
+def test_data_parallel_runner_with_the_split_train_step(tmp_path):
+    """NeRFRunner(split_train=True) under a launcher: one rank over a real RCCL group must leave bit-identical weights, losses and frames to the
+    plain single-process runner with the same switch (gradients in the flat bucket, the sum of the three weight-gradient sets written into
+    its views), and it learns."""
+    import torch
+
+    plain = _run_ranks(0, str(tmp_path / "plain"), ("--split-train",))
+    dp = _run_ranks(1, str(tmp_path / "dp1"), ("--split-train", "--force-dist"))
+    assert dp["distributed"] is True and dp["ranks"] == 1
+    assert plain["losses"] == dp["losses"] and torch.equal(plain["weights"], dp["weights"]) and torch.equal(plain["frame"], dp["frame"])
+    assert dp["losses"][-1] < 0.6 * dp["losses"][0]
+    exact = _run_ranks(0, str(tmp_path / "exact"))
+    assert abs(exact["losses"][0] - plain["losses"][0]) <= 1e-5 * abs(exact["losses"][0])  # the same first step to the split arithmetic's 1e-5
+
+
+@pytest.mark.timeout(900)
 def test_data_parallel_runner_two_ranks_follow_the_single_process_run(tmp_path):
     """Two ranks on the box's one GPU (process group over gloo: RCCL refuses two ranks on one device; same runner code): each trains on
     its half of every 256-ray batch, the halves' gradients are SUM-all-reduced, both take the same Adam step.  The job's loss curve (the

@@ -2,7 +2,7 @@
 child process (the runner reads RANK / WORLD_SIZE / LOCAL_RANK from the environment before its first GPU call; nothing is re-exec'd).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        tests/tools/dp_runner_rank.py OUT_DIR [--bf16] [--iters K] [--batch B] [--force-dist] [--overlap]
+        tests/tools/dp_runner_rank.py OUT_DIR [--bf16] [--split-train] [--iters K] [--batch B] [--force-dist] [--overlap]
 
 N = 1: a real RCCL group (backend "nccl").  N = 2 on the one GPU of a test box: NERF_DIST_BACKEND=gloo (RCCL refuses two ranks on one
 device), both ranks on cuda:0 -- the same runner code, the collectives through the host.
@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--split-train", action="store_true", help="NeRFRunner(split_train=True): the train step in split-fp32 arithmetic")
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--force-dist", action="store_true", help="join a process group also as a single rank")
@@ -39,7 +40,7 @@ def main():
     kw = dict(gpu=0, img_dir="", results_path=os.path.join(args.out, "res") + "/", ckpt_path=os.path.join(args.out, "ck") + "/", low_res=1,
               total_iter=args.iters, batch_ray=args.batch, learning=1e-3, lr_gamma=0.1, lr_milestone=[10, 200], n_coarse=32, n_fine=64,
               data_type="sync", step=args.iters // 2, decay_end=10000, sched="EXP", datasets={"train": scene, "val": scene, "test": scene},
-              log_every=1, bf16_mlp=args.bf16, on_resample_fault="warn")
+              log_every=1, bf16_mlp=args.bf16, split_train=args.split_train, on_resample_fault="warn")
     run = P.NeRFRunner(continue_=False, distributed=True if args.force_dist else None, overlap_allreduce=True if args.overlap else None, **kw)
     losses = []
     wrote = []
