@@ -172,7 +172,7 @@ class NeRFModel(nn.Module):
         self.bf16_mlp = False
         #: INFERENCE calls (no grad) only: evaluate the fp32 MLP on bf16 MFMA with every fp32 operand split into two bf16 parts (hi + mid)
         #: and three MFMAs per product, fp32 accumulation -- inside the same 1e-4 bar as the exact-fp32 default,
-        #: 3x faster.  Off by default: the default keeps exact k-ordered fp32 fma chains; training forwards ignore it
+        #: 3x faster.  Off by default: the default keeps exact k-ordered fp32 fma chains; training forwards ignore it (their switch is split_train)
         self.split_mlp = False
         #: TRAINING calls (a forward that records a graph, train_step): the whole train step in split-fp32 arithmetic -- every fp32 operand of
         #: the forward, the dX chain and the weight-gradient products as two bf16 parts (hi + mid), three bf16 MFMAs per product, fp32
