@@ -387,8 +387,8 @@ def rooflines(leg, prof, b_local, steps):
                    FLOP_PER_SAMPLE * b_local * (NC + NF) // 2, fwd_key, EXEC_FLOP_PER_SAMPLE / FLOP_PER_SAMPLE)
     if getattr(leg, "split", False) and leg.train:
         # the opt-in split-fp32 TRAIN step: forward (field_fwd_split<SAVE>), dX chain (field_bwd_split) on the bf16 pipe with THREE bf16 MFMAs per fp32
-        # product -- executed bf16 FLOPs against the dense bf16 peak -- and the weight gradients as three passes of the bf16 products (hi x hi,
-        # hi x mid, mid x hi): HBM-bound like the bf16 variant's, three times its operand bytes
+        # product -- executed bf16 FLOPs against the dense bf16 peak -- and the weight gradients as the two-part instantiations of the bf16 products
+        # (one pass over G_hi, G_mid, X_hi, X_mid): HBM-bound like the bf16 variant's, TWICE its operand bytes
         fwd = split_block()
         fwd["traffic"] = scaled(read_traffic(leg, ["k_field_fwd_split<true>"]))
         cms = sum(prof.get(k, (0.0, 0))[0] for k in ("bwd_field_fine", "bwd_field_coarse"))
@@ -404,10 +404,10 @@ def rooflines(leg, prof, b_local, steps):
                  "flop_per_launch": cexe, "achieved_algorithmic_fp32": round(calg / (cavg * 1e-3) / 1e12, 2) if cavg > 0 else 0.0}
         dw_ms = prof.get("bwd_dw", (0.0, 0))[0] / max(prof.get("bwd_dw", (0.0, 1))[1], 1)
         wb = ((b_local * NC + 255) // 256 + (b_local * NF + 255) // 256) * 8
-        dw_bytes = 3 * DW_BF16_KIB_PER_WAVE_BLOCK * 1024 * wb
+        dw_bytes = 2 * DW_BF16_KIB_PER_WAVE_BLOCK * 1024 * wb
         dw = {"bound": "hbm", "achieved": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1) if dw_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
               "frac": round(dw_bytes / (dw_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if dw_ms > 0 else 0.0, "traffic": None, "traffic_source": src,
-              "kernel": "k_dw_bf16 x 3 (hi x hi, hi x mid, mid x hi passes of the weight-gradient products + reduces + the sum of the three sets)",
+              "kernel": "k_dw_bf16<.., SPLIT> (the weight-gradient products over two-part operands, one pass + the slab reduce)",
               "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "bytes_per_launch": dw_bytes}
         for blk in (fwd, chain):
             if blk.get("traffic") and blk["avg_launch_ms"] > 0:

@@ -72,7 +72,7 @@ enum {
                                           Without NERF_HIP_SAVE_FOR_BACKWARD (inference): within the same 1e-4 bar as the exact-fp32 default
                                           (measured 3e-6 / 2e-5 against the reference's outputs), 3x its rate.  WITH it (the split-fp32 TRAIN
                                           step; pass the flag to nerf_hip_backward / nerf_hip_train_step as well): forward, dX chain and
-                                          weight-gradient products in that arithmetic, 2x the exact step's rate, loss to 1e-5, gradients inside
+                                          weight-gradient products in that arithmetic, 2.1x the exact step's rate, loss to 1e-5, gradients inside
                                           the bands the exact path is held to.  Off by default: the default keeps exact k-ordered fp32 fma
                                           chains.  Ignored with NERF_HIP_BF16_MLP */
   NERF_HIP_CORRECTED = 1 << 5,         /* OPTIONAL EXTRA, off by default, NOT the reference's results (SURVEY.md 8a "Q": reproduce the quirks by

@@ -174,8 +174,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
       L.bslabs = take(dw_bf16_slab_floats() * 4);
       L.mbuf = take((size_t)HALF * WIDTH * 4);
     } else if (flags & NERF_HIP_SPLIT_MLP) {
-      // split-fp32 training: the bf16 variant's fragment-layout buffers twice (hi parts, mid parts); the weight-gradient products run three
-      // times over them (hi x hi, hi x mid, mid x hi) into three gradient sets that are summed at the end
+      // split-fp32 training: the bf16 variant's fragment-layout buffers twice (hi parts, mid parts)
       const size_t wb = wave_blocks(B, Nc) + wave_blocks(B, Nf);
       L.packed_sp_bwd = take(split_bwd_image_bytes());
       L.bsave = take(wb * BS_TOTAL_KS * BF_FRAG_BYTES);
@@ -184,8 +183,7 @@ WsLayout layout(int B, int Nc, int Nf, int flags) {
       L.bG = take(wb * BG_TOTAL_KS * BF_FRAG_BYTES);
       L.bG2 = take(wb * BG_TOTAL_KS * BF_FRAG_BYTES);
       L.bslabs = take(dw_bf16_slab_floats() * 4);
-      L.mbuf = take((size_t)3 * HALF * WIDTH * 4);
-      L.dwtmp = take((size_t)2 * SPLIT_GRAD_SET_FLOATS * 4);
+      L.mbuf = take((size_t)HALF * WIDTH * 4);
     } else {
       L.save = take((size_t)NSAVE * (Mtot + DUMP_ROWS) * WIDTH * 4);  // + dump rows (kernels.h: MSrows)
       L.masks = take((size_t)8 * tiles * 4 * 256 * 2);
@@ -218,14 +216,6 @@ int check_device() {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(NERF_HIP_ERR_ARCH, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
   checked_dev = dev;
   return NERF_HIP_OK;
-}
-
-// elements of tensor t of weights24 / dweights24 (include/nerf_hip.h: NeRFModel.network.parameters() order)
-int param_numel(int t) {
-  static const int n[24] = {WIDTH * POINT_DIM, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH * (WIDTH + POINT_DIM), WIDTH,
-                            WIDTH * WIDTH, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH * WIDTH, WIDTH, WIDTH, 1, WIDTH * WIDTH, WIDTH, HALF * (WIDTH + DIR_DIM), HALF,
-                            3 * HALF, 3};
-  return n[t];
 }
 
 int check_weights(const float* const* w) {
@@ -672,10 +662,10 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   { ProfScope ps(NERF_HIP_K_BWD_FIELD_COARSE, st, &pc); HIP_TRY(chain(fb, false)); }
 
   // 5. weight gradients: dW = G^T X over all B*(Nc+Nf) samples
-  // the bf16 products over ONE pair of fragment-layout buffers (layer inputs `bs`, pre-activation gradients `bg`) into one set of 24 gradient
-  // tensors `dwp` and the folded product's M (`mbuf`); `fold`: finish with k_fold_grads.  The bf16-MLP variant calls it once; the split-fp32
-  // train step three times (hi x hi, hi x mid, mid x hi) and sums the sets.
-  auto dw_bf16_phase = [&](const unsigned char* bs, const unsigned char* bg, float* const* dwp, float* mbuf, void* ev, bool fold) -> int {
+  // the bf16 products over a pair of fragment-layout buffers (layer inputs `bs`, pre-activation gradients `bg`) into the 24 gradient tensors `dwp`
+  // and the folded product's M (`mbuf`); `fold`: finish with k_fold_grads.  `sp` != {0, 0}: the split-fp32 train step -- `bs` / `bg` hold the hi
+  // parts, the mid parts lie sp.xdelta / sp.gdelta bytes behind, and every product is formed as hi x hi + hi x mid + mid x hi in ONE pass.
+  auto dw_bf16_phase = [&](const unsigned char* bs, const unsigned char* bg, float* const* dwp, float* mbuf, void* ev, bool fold, DwBfSplit sp) -> int {
     float* slabs = at<float>(ws, L.bslabs);
     const float* const slab_limit = slabs + dw_bf16_slab_floats();  // checked by launch_dw_bf16_multi before it enqueues anything
     auto X = [&](int t) { return bs + (size_t)wb_tot * bs_cum(t) * BF_FRAG_BYTES; };
@@ -717,15 +707,15 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       };
       float* end = slabs;
       if (ev) {
-        HIP_TRY(launch_dw_bf16_multi(pr, n_early, wb_tot, slabs, slab_limit, &end, st));
+        HIP_TRY(launch_dw_bf16_multi(pr, n_early, wb_tot, slabs, slab_limit, &end, st, sp));
         early_reds();
         HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
         HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev), st));
         rb.n = 0;
-        HIP_TRY(launch_dw_bf16_multi(pr + n_early, n - n_early, wb_tot, end, slab_limit, &end, st));
+        HIP_TRY(launch_dw_bf16_multi(pr + n_early, n - n_early, wb_tot, end, slab_limit, &end, st, sp));
         late_reds();
       } else {
-        HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, slab_limit, &end, st));
+        HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, slab_limit, &end, st, sp));
         early_reds();
         late_reds();
       }
@@ -747,7 +737,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       const unsigned char* Gs[6];
       const unsigned char* Xs[6];
       for (int k = 0; k < 6; ++k) { Gs[k] = Gt(BG_L0 + layers[k]); Xs[k] = X(BS_H0 + layers[k] - 1); }
-      HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st));
+      HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st, sp));
       for (int k = 0; k < 6; ++k)
         red(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dwp[2 * layers[k]], WIDTH, 0, dwp[2 * layers[k] + 1]);
       slabs += (size_t)6 * ns * 256 * 257;
@@ -755,7 +745,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       memset(pr, 0, sizeof(pr));
       int n = 0, i_l4 = -1;
       if (small_group == 1) {
-        HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
+        HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st, sp));
         red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dwp[8], WIDTH + POINT_DIM, 0, dwp[9]);
         slabs += (size_t)ns * 256 * 321;
       } else {
@@ -769,7 +759,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       const int i_c = n;
       pr[n++] = DwBfProd{Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, nullptr, 0};
       float* end = slabs;
-      HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, slab_limit, &end, st));
+      HIP_TRY(launch_dw_bf16_multi(pr, n, wb_tot, slabs, slab_limit, &end, st, sp));
       if (i_l4 >= 0) red(pr[i_l4].slabs, pr[i_l4].nslab, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dwp[8], WIDTH + POINT_DIM, 0, dwp[9]);
       red(pr[i_l0].slabs, pr[i_l0].nslab, 256, 64, 0, 256, 0, POINT_DIM, dwp[0], POINT_DIM, 0, dwp[1]);
       red(pr[i_d].slabs, pr[i_d].nslab, 160, 288, 0, HALF, 0, DIR_DIM, dwp[W_DIR], WIDTH + DIR_DIM, 0, dwp[B_DIR]);
@@ -785,7 +775,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       return NERF_HIP_OK;
     }
     // layer 0: X = gamma_p
-    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0), 16, X(BS_GP), 4, nullptr, 0, nullptr, wb_tot, slabs, &ns, st, sp));
     red(slabs, ns, 256, 64, 0, 256, 0, POINT_DIM, dwp[0], POINT_DIM, 0, dwp[1]);
     slabs += (size_t)ns * 256 * 65;
     {  // layers 1, 2, 3, 5, 6, 7: six 256 x 256 products in ONE launch (42 workgroups each: a sixth of the slab traffic)
@@ -793,13 +783,13 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
       const unsigned char* Gs[6];
       const unsigned char* Xs[6];
       for (int k = 0; k < 6; ++k) { Gs[k] = Gt(BG_L0 + layers[k]); Xs[k] = X(BS_H0 + layers[k] - 1); }
-      HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st));
+      HIP_TRY(launch_dw_bf16_group(Gs, Xs, 6, wb_tot, slabs, &ns, st, sp));
       for (int k = 0; k < 6; ++k)
         red(slabs + (size_t)k * ns * 256 * 257, ns, 256, 256, 0, 256, 0, WIDTH, dwp[2 * layers[k]], WIDTH, 0, dwp[2 * layers[k] + 1]);
       slabs += (size_t)6 * ns * 256 * 257;
     }
     // layer 4: one pass over dpre4 for both column groups of the [256][316] matrix: X = [h3 | gamma_p]
-    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_L0 + 4), 16, X(BS_H0 + 3), 16, X(BS_GP), 4, nullptr, wb_tot, slabs, &ns, st, sp));
     red(slabs, ns, 256, 320, 0, 256, 0, WIDTH + POINT_DIM, dwp[8], WIDTH + POINT_DIM, 0, dwp[9]);
     slabs += (size_t)ns * 256 * 321;
     if (ev) {  // point_layer[0..7] are complete here: their sums go out now, the rest of the products follow the event
@@ -809,13 +799,13 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
     }
     // point_info folded into dir_info (bf16_common.h): ONE product dpre_dir^T [gamma_d | h7] -- columns 0..23 are dir_info's direction
     // columns, columns 32.. are M = dpre_dir^T h7 (-> k_fold_grads below) -- and in the same pass over h7 the sigma head: row 3 of h7^T (dz, dspre)
-    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_D), 8, X(BS_GD), 2, X(BS_H0 + 7), 16, Gt(BG_Z), wb_tot, slabs, &ns, st, sp));
     red(slabs, ns, 160, 288, 0, HALF, 0, DIR_DIM, dwp[W_DIR], WIDTH + DIR_DIM, 0, dwp[B_DIR]);
     red(slabs, ns, 160, 288, 0, HALF, 32, WIDTH, mbuf, WIDTH, 0, nullptr);
     red(slabs, ns, 160, 288, HALF + 3, 1, 32, WIDTH, dwp[W_SIGMA], WIDTH, 0, nullptr);
     slabs += (size_t)ns * 160 * 289;
     // colour head = rows 0..2 of the (dz, dspre) tile against c; row 3 of its column sums = the sigma bias gradient
-    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, wb_tot, slabs, &ns, st));
+    HIP_TRY(launch_dw_bf16_gemm(Gt(BG_Z), 2, X(BS_C), 8, nullptr, 0, nullptr, wb_tot, slabs, &ns, st, sp));
     red(slabs, ns, 32, 128, 0, 3, 0, HALF, dwp[W_COLOR], HALF, 0, dwp[B_COLOR]);
     red(slabs, ns, 32, 128, 3, 1, 0, 0, nullptr, 0, 0, dwp[B_SIGMA]);
     HIP_TRY(launch_dw_bf16_reduce_batch(rb, st));
@@ -829,47 +819,15 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   };
   if (bf16) {
     ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
-    if (int rc = dw_bf16_phase(at<unsigned char>(ws, L.bsave), at<unsigned char>(ws, L.bG), dw, at<float>(ws, L.mbuf), early_event, true)) return rc;
+    if (int rc = dw_bf16_phase(at<unsigned char>(ws, L.bsave), at<unsigned char>(ws, L.bG), dw, at<float>(ws, L.mbuf), early_event, true, DwBfSplit{})) return rc;
   } else if (split) {
     // split-fp32 train step: G = G_hi + G_mid, X = X_hi + X_mid (bf16 parts, fragment layout): G^T X = G_hi^T X_hi + G_hi^T X_mid + G_mid^T X_hi
-    // + O(2^-16): three passes of the bf16 products into three gradient sets.  The column sums of G (every bias gradient) ride on each pass:
-    // pass 1 carries sum G_hi a second time, so the biases take passes 0 and 2 only.  k_fold_grads is linear in M and db_dir: once, on the sums.
+    // + O(2^-16), formed block by block inside the two-part instantiations of the bf16 products (dw_bf16.hip): ONE pass over the four buffers
     ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
-    float* set1[24];
-    float* set2[24];
-    {
-      float* base = at<float>(ws, L.dwtmp);
-      size_t o = 0;
-      for (int t = 0; t < 24; ++t) {
-        set1[t] = base + o;
-        set2[t] = base + SPLIT_GRAD_SET_FLOATS + o;
-        o += ((size_t)param_numel(t) + 63) / 64 * 64;
-      }
-      if (o > (size_t)SPLIT_GRAD_SET_FLOATS) return fail(NERF_HIP_ERR_WORKSPACE, "split gradient scratch too small");
-    }
-    HIP_TRY(hipMemsetAsync(at<float>(ws, L.dwtmp), 0, (size_t)2 * SPLIT_GRAD_SET_FLOATS * sizeof(float), st));  // (tensors a pass does not write -- point_info's, dir_info's feature columns -- must not carry stale bits into the sum)
-    float* m0 = at<float>(ws, L.mbuf);
-    float* m1 = m0 + (size_t)HALF * WIDTH;
-    float* m2 = m1 + (size_t)HALF * WIDTH;
-    const unsigned char* xh = at<unsigned char>(ws, L.bsave);
-    const unsigned char* xm = at<unsigned char>(ws, L.bsave2);
-    const unsigned char* gh = at<unsigned char>(ws, L.bG);
-    const unsigned char* gm = at<unsigned char>(ws, L.bG2);
-    if (int rc = dw_bf16_phase(xh, gh, dw, m0, nullptr, false)) return rc;
-    if (int rc = dw_bf16_phase(xm, gh, set1, m1, nullptr, false)) return rc;
-    if (int rc = dw_bf16_phase(xh, gm, set2, m2, nullptr, false)) return rc;
-    SplitSumArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    for (int t = 0; t < 24; ++t) { sa.out[t] = dw[t]; sa.a[t] = set1[t]; sa.b[t] = set2[t]; sa.numel[t] = param_numel(t); }
-    sa.bias_mask = 0;
-    for (int t = 1; t < 24; t += 2) sa.bias_mask |= 1u << t;  // odd tensors = biases (weights24 order)
-    sa.m0 = m0; sa.m1 = m1; sa.m2 = m2; sa.m_numel = HALF * WIDTH;
-    HIP_TRY(launch_split_grad_sum(sa, st));
-    FoldGradArgs fg;
-    fg.M = m0; fg.db_dir = dw[B_DIR]; fg.w_dir = w.p[W_DIR]; fg.w_pi = w.p[W_PI]; fg.b_pi = w.p[B_PI];
-    fg.dW_pi = dw[W_PI]; fg.db_pi = dw[B_PI]; fg.dW_dir = dw[W_DIR];
-    HIP_TRY(launch_fold_grads(fg, st));
-    if (early_event) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(early_event), st));  // (no early part in this mode: everything is final here)
+    DwBfSplit sp;
+    sp.xdelta = (long long)L.bsave2 - (long long)L.bsave;
+    sp.gdelta = (long long)L.bG2 - (long long)L.bG;
+    if (int rc = dw_bf16_phase(at<unsigned char>(ws, L.bsave), at<unsigned char>(ws, L.bG), dw, at<float>(ws, L.mbuf), early_event, true, sp)) return rc;
   } else {
     ProfScope ps(NERF_HIP_K_BWD_DW, st, &pc);
     DwBatch batch;

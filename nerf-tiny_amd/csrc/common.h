@@ -78,7 +78,7 @@ struct WsLayout {
   size_t status, dbg, packed, packed_bf, packed_sp, fold, rayf, dvec, t_c, sig_c, rgb_c, w_c, t_f, sig_f, rgb_f;
   // training-only
   size_t packed_bf_bwd, bsave, bmask, bG, bslabs;  // bf16-MLP training (fragment layout, bf16_common.h)
-  size_t packed_sp_bwd, bsave2, bG2, dwtmp;        // split-fp32 training: transposed hi / mid image, the mid-part buffers, two scratch gradient sets
+  size_t packed_sp_bwd, bsave2, bG2;               // split-fp32 training: transposed hi / mid image, the mid-part buffers
   size_t perm, w_m, bundle, save, masks, spre, G, dz, dspre, drgb_c, dsig_c, drgb_f, dsig_f, dt_f, slabs, sbuf, gdbuf, mbuf, dC;
   size_t total;
 };

@@ -41,6 +41,9 @@ struct DwBfArgs {
   int x1_ks;
   int wb_tot;
   float* slabs;             // [product][workgroup][o_tiles*32 (+32 with Z)][NIT*32 + 1]  (last column: sum of G over the samples)
+  // split-fp32 train step (SPLIT instantiations): every operand is a (hi, mid) pair of bf16 tensors of the same layout; the mid part of a
+  // gradient-type tensor (G, Z) lies gdelta bytes behind its hi part, the mid part of an input tensor (X1, X2) xdelta bytes
+  long long gdelta, xdelta;
 };
 
 // LDS unit (16 bytes) of (piece ks, half h, sample s) inside a tensor block: the sample index is XOR-swizzled
@@ -61,24 +64,28 @@ __device__ __forceinline__ u32x4 dwb_operand(const unsigned char* blk, int t, in
   return r;
 }
 
-template <int NIT, bool HAS_Z>
+template <int NIT, bool HAS_Z, bool SPLIT = false>
 struct DwbGeom {
   static constexpr int XKS = 2 * NIT;
-  static constexpr int PIECES = 16 + XKS + (HAS_Z ? 2 : 0);   // slot layout: G at piece 0, X at 16, Z at 16 + XKS
-  static constexpr int SLOT_BYTES = PIECES * BF_FRAG_BYTES;
+  static constexpr int PIECES = 16 + XKS + (HAS_Z ? 2 : 0);   // slot layout: G at piece 0, X at 16, Z at 16 + XKS; SPLIT: the mid parts behind, same order
+  static constexpr int SLOT_PIECES = (SPLIT ? 2 : 1) * PIECES;
+  static constexpr int SLOT_BYTES = SLOT_PIECES * BF_FRAG_BYTES;
   // ring slots: three blocks in flight are enough where a block is 32+ KiB; the products with small blocks (layer 0: 20 KiB, colour head:
-  // 10 KiB used) were paced by the per-block latency (3.4-3.8 TB/s, profiles/r03_train_bf16_pmc.json): they get as many slots as fit
-  static constexpr int NSLOT = PIECES <= 20 ? 7 : (PIECES <= 26 ? 6 : 4);
+  // 10 KiB used) were paced by the per-block latency (3.4-3.8 TB/s, profiles/r03_train_bf16_pmc.json): they get as many slots as fit.
+  // SPLIT (two-part operands: twice the bytes per block): what fits 160 KiB, at most four -- two for the 256 x 256 products (64 KiB per block:
+  // one being multiplied, one in flight)
+  static constexpr int NSLOT_FIT = (160 * 1024) / SLOT_BYTES;
+  static constexpr int NSLOT = SPLIT ? (NSLOT_FIT > 4 ? 4 : NSLOT_FIT) : (PIECES <= 20 ? 7 : (PIECES <= 26 ? 6 : 4));
   static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;
-  static constexpr int NPW = (PIECES + 7) / 8;                // loads per wave and block
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static constexpr int NPW = (SLOT_PIECES + 7) / 8;           // loads per wave and block
+  static_assert(NSLOT >= 2 && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 // The body of one workgroup: product `gi` of the argument block, workgroup `wg` of the `nwg` that share that product's samples; its
 // partial sums go to slab_base + wg * rows * ld.
-template <int NIT, bool HAS_Z>
+template <int NIT, bool HAS_Z, bool SPLIT = false>
 __device__ __forceinline__ void dw_bf16_body(const DwBfArgs& a, unsigned char* lds, const int gi, const int wg, const int nwg, float* slab_base) {
-  using Geo = DwbGeom<NIT, HAS_Z>;
+  using Geo = DwbGeom<NIT, HAS_Z, SPLIT>;
   constexpr int XKS = Geo::XKS, NSLOT = Geo::NSLOT, NPW = Geo::NPW;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -108,7 +115,11 @@ __device__ __forceinline__ void dw_bf16_body(const DwBfArgs& a, unsigned char* l
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
       int pc = wv + 8 * k;
-      pc = pc < total ? pc : total - 1;
+      constexpr int SETS = SPLIT ? 2 : 1;
+      pc = pc < SETS * total ? pc : SETS * total - 1;
+      const bool mid = SPLIT && pc >= total;  // SPLIT: pieces [total, 2 total) are the mid parts, slot pieces Geo::PIECES ..
+      if (mid) pc -= total;
+      const long long gd = mid ? a.gdelta : 0, xd = mid ? a.xdelta : 0;
       const unsigned char* src;
       int ks, dst;
       // (timing experiments only, results wrong: NERF_TIMING_DW_HALF_G / _X read every second piece twice -> half the distinct bytes of
@@ -126,15 +137,16 @@ __device__ __forceinline__ void dw_bf16_body(const DwBfArgs& a, unsigned char* l
 #endif
       if (pc < gks) {
         ks = pc; dst = ks;
-        src = gG + ((size_t)wb * gks + DWB_GSRC(ks)) * BF_FRAG_BYTES;
+        src = gG + gd + ((size_t)wb * gks + DWB_GSRC(ks)) * BF_FRAG_BYTES;
       } else if (pc < gks + XKS) {
         const int x = pc - gks;
         ks = x; dst = 16 + x;  // parity of the slot piece = parity of x (x1_ks is even)
-        src = x < x1 ? gX1 + ((size_t)wb * x1 + DWB_XSRC(x)) * BF_FRAG_BYTES : a.X2 + ((size_t)wb * (XKS - x1) + DWB_XSRC(x - x1)) * BF_FRAG_BYTES;
+        src = (x < x1 ? gX1 + ((size_t)wb * x1 + DWB_XSRC(x)) * BF_FRAG_BYTES : a.X2 + ((size_t)wb * (XKS - x1) + DWB_XSRC(x - x1)) * BF_FRAG_BYTES) + xd;
       } else {
         ks = pc - gks - XKS; dst = 16 + XKS + ks;
-        src = a.Z + ((size_t)wb * 2 + ks) * BF_FRAG_BYTES;
+        src = a.Z + gd + ((size_t)wb * 2 + ks) * BF_FRAG_BYTES;
       }
+      if (mid) dst += Geo::PIECES;
       const int h = lane >> 5, s = (lane & 31) ^ (4 * (2 * (ks & 1) + h));
       glds16(src + (h * 32 + s) * 16, lds_base + slot * Geo::SLOT_BYTES + dst * BF_FRAG_BYTES);  // (the non-temporal form measured the same)
     }
@@ -149,19 +161,40 @@ __device__ __forceinline__ void dw_bf16_body(const DwBfArgs& a, unsigned char* l
       dma_block(b + NSLOT - 1, (b + NSLOT - 1) % NSLOT);  // into the slot of block b - 1
       const unsigned char* gb = lds + (b % NSLOT) * Geo::SLOT_BYTES;
       const unsigned char* xb = gb + 16 * BF_FRAG_BYTES;
+      constexpr int MID = Geo::PIECES * BF_FRAG_BYTES;  // SPLIT: the mid parts of the block sit this far behind their hi parts
       if (worker) {
 #pragma unroll
         for (int kstep = 0; kstep < 2; ++kstep) {
           const u32x4 A = dwb_operand(gb, wv, kstep, lane);
+          if constexpr (SPLIT) {  // G^T X = G_hi^T X_hi + G_hi^T X_mid + G_mid^T X_hi (+ O(2^-16)), the small products first; column sums of G_hi + G_mid
+            const u32x4 Am = dwb_operand(gb + MID, wv, kstep, lane);
 #pragma unroll
-          for (int i = 0; i < NIT; ++i) acc[i] = bf_mfma(A, dwb_operand(xb, i, kstep, lane), acc[i]);
-          accb = bf_mfma(A, ones, accb);
+            for (int i = 0; i < NIT; ++i) {
+              const u32x4 Bh = dwb_operand(xb, i, kstep, lane);
+              acc[i] = bf_mfma(Am, Bh, acc[i]);
+              acc[i] = bf_mfma(A, dwb_operand(xb + MID, i, kstep, lane), acc[i]);
+              acc[i] = bf_mfma(A, Bh, acc[i]);
+            }
+            accb = bf_mfma(Am, ones, accb);
+            accb = bf_mfma(A, ones, accb);
+          } else {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) acc[i] = bf_mfma(A, dwb_operand(xb, i, kstep, lane), acc[i]);
+            accb = bf_mfma(A, ones, accb);
+          }
         }
       }
       if (zworker) {  // rows = this wave's X tile, columns = Z features: (X^T Z) tile
         const unsigned char* zb = xb + XKS * BF_FRAG_BYTES;
 #pragma unroll
-        for (int kstep = 0; kstep < 2; ++kstep) accz = bf_mfma(dwb_operand(xb, zt, kstep, lane), dwb_operand(zb, 0, kstep, lane), accz);
+        for (int kstep = 0; kstep < 2; ++kstep) {
+          const u32x4 Xh = dwb_operand(xb, zt, kstep, lane), Zh = dwb_operand(zb, 0, kstep, lane);
+          if constexpr (SPLIT) {
+            accz = bf_mfma(dwb_operand(xb + MID, zt, kstep, lane), Zh, accz);
+            accz = bf_mfma(Xh, dwb_operand(zb + MID, 0, kstep, lane), accz);
+          }
+          accz = bf_mfma(Xh, Zh, accz);
+        }
       }
     }
     wait_vmcnt<0>();  // nothing may still be writing this workgroup's LDS when it ends
@@ -189,12 +222,12 @@ __device__ __forceinline__ void dw_bf16_body(const DwBfArgs& a, unsigned char* l
   }
 }
 
-template <int NIT, bool HAS_Z>
+template <int NIT, bool HAS_Z, bool SPLIT = false>
 __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16(const DwBfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int gi = blockIdx.x % a.ngemm, wg = blockIdx.x / a.ngemm, nwg = gridDim.x / a.ngemm;
   const int rows = a.o_tiles * 32 + (HAS_Z ? 32 : 0);
-  dw_bf16_body<NIT, HAS_Z>(a, lds, gi, wg, nwg, a.slabs + (size_t)gi * nwg * rows * (NIT * 32 + 1));
+  dw_bf16_body<NIT, HAS_Z, SPLIT>(a, lds, gi, wg, nwg, a.slabs + (size_t)gi * nwg * rows * (NIT * 32 + 1));
 }
 
 // ---- SMALL batches: every product of the step (or of its early / late part) in ONE launch -------------------------------------------
@@ -211,6 +244,7 @@ struct DwBfMulti {
   int n;
 };
 
+template <bool SPLIT>
 __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16_multi(const DwBfMulti m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int i = 0;
@@ -220,11 +254,11 @@ __global__ __launch_bounds__(BF_WG, 1) void k_dw_bf16_multi(const DwBfMulti m) {
   const DwBfArgs& a = m.a[i];
   const int wg = blockIdx.x - m.wg0[i], nwg = m.wg0[i + 1] - m.wg0[i];
   switch (m.kind[i]) {
-    case 2 * 10 + 0: dw_bf16_body<10, false>(a, lds, 0, wg, nwg, a.slabs); break;
-    case 2 * 9 + 1: dw_bf16_body<9, true>(a, lds, 0, wg, nwg, a.slabs); break;
-    case 2 * 8 + 0: dw_bf16_body<8, false>(a, lds, 0, wg, nwg, a.slabs); break;
-    case 2 * 4 + 0: dw_bf16_body<4, false>(a, lds, 0, wg, nwg, a.slabs); break;
-    case 2 * 2 + 0: dw_bf16_body<2, false>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 10 + 0: dw_bf16_body<10, false, SPLIT>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 9 + 1: dw_bf16_body<9, true, SPLIT>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 8 + 0: dw_bf16_body<8, false, SPLIT>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 4 + 0: dw_bf16_body<4, false, SPLIT>(a, lds, 0, wg, nwg, a.slabs); break;
+    case 2 * 2 + 0: dw_bf16_body<2, false, SPLIT>(a, lds, 0, wg, nwg, a.slabs); break;
     default: break;
   }
 }
@@ -320,20 +354,26 @@ size_t dw_bf16_slab_floats() {
   return (size_t)DWB_WGS * 256 * 65 + (size_t)6 * (DWB_WGS / 6) * 256 * 257 + (size_t)DWB_WGS * 256 * 321 + (size_t)DWB_WGS * 160 * 289 + (size_t)DWB_WGS * 32 * 129;
 }
 
+template <int NIT, bool HAS_Z, bool SPLIT>
+static hipError_t dwb_launch_as(const DwBfArgs& a, int wgs, hipStream_t st) {
+  static std::atomic<unsigned long long> opted{0};
+  using Geo = DwbGeom<NIT, HAS_Z, SPLIT>;
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_dw_bf16<NIT, HAS_Z, SPLIT>)}, Geo::LDS_BYTES)) return e;
+  hipLaunchKernelGGL((k_dw_bf16<NIT, HAS_Z, SPLIT>), dim3(wgs), dim3(BF_WG), Geo::LDS_BYTES, st, a);
+  return hipGetLastError();
+}
+// (a.gdelta / a.xdelta != 0: the two-part form of the split-fp32 train step)
 template <int NIT, bool HAS_Z>
 static hipError_t dwb_launch(const DwBfArgs& a, int wgs, hipStream_t st) {
-  static std::atomic<unsigned long long> opted{0};
-  using Geo = DwbGeom<NIT, HAS_Z>;
-  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_dw_bf16<NIT, HAS_Z>)}, Geo::LDS_BYTES)) return e;
-  hipLaunchKernelGGL((k_dw_bf16<NIT, HAS_Z>), dim3(wgs), dim3(BF_WG), Geo::LDS_BYTES, st, a);
-  return hipGetLastError();
+  return (a.gdelta || a.xdelta) ? dwb_launch_as<NIT, HAS_Z, true>(a, wgs, st) : dwb_launch_as<NIT, HAS_Z, false>(a, wgs, st);
 }
 
 // One pass over the samples: slabs <- G^T [X1 | X2]  (+ [X1 | X2]^T Z in 32 extra slab rows).  x1_ks + x2_ks in {2,4,8,16,18,20}.
 hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned char* X1, int x1_ks, const unsigned char* X2, int x2_ks,
-                               const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st) {
+                               const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st, DwBfSplit sp) {
   DwBfArgs a;
   memset(&a, 0, sizeof(a));
+  a.gdelta = sp.gdelta; a.xdelta = sp.xdelta;
   a.z_tile0 = Z ? x1_ks / 2 : 0;  // Z multiplies the X2 tiles (the sigma head rides on the product whose second input tensor is h7)
   a.G[0] = G; a.X1[0] = X1; a.ngemm = 1; a.X2 = X2 ? X2 : X1; a.Z = Z; a.g_ks = g_ks; a.o_tiles = (g_ks + 1) / 2; a.x1_ks = x1_ks; a.wb_tot = wb_tot; a.slabs = slabs;
   const int wgs = wb_tot < DWB_WGS ? wb_tot : DWB_WGS;
@@ -353,10 +393,11 @@ hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned 
 
 // n (<= 6) products G_k^T X_k of 256 x 256 outputs in one launch; product k's slabs start at slabs + k * (*nslab) * 256 * 257
 hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned char* const* Xs, int n, int wb_tot, float* slabs, int* nslab,
-                                hipStream_t st) {
+                                hipStream_t st, DwBfSplit sp) {
   if (n < 1 || n > 6) return hipErrorInvalidValue;
   DwBfArgs a;
   memset(&a, 0, sizeof(a));
+  a.gdelta = sp.gdelta; a.xdelta = sp.xdelta;
   for (int k = 0; k < n; ++k) { a.G[k] = Gs[k]; a.X1[k] = Xs[k]; }
   a.X2 = Xs[0]; a.ngemm = n; a.g_ks = 16; a.o_tiles = 8; a.x1_ks = 16; a.wb_tot = wb_tot; a.slabs = slabs;
   int nwg = DWB_WGS / n;
@@ -368,7 +409,7 @@ hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned c
 // n (<= 12) products of ANY of the shapes above in ONE launch of (at most) DWB_WGS workgroups, dealt out in proportion to the bytes a
 // product reads per wave block (largest remainder, at least one each, never more than wave blocks).  Fills p[i].slabs / p[i].nslab
 // (carved from slab_base in order) and returns the end of the used slab space in *slab_end.
-hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, const float* slab_limit, float** slab_end, hipStream_t st) {
+hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, const float* slab_limit, float** slab_end, hipStream_t st, DwBfSplit sp) {
   if (n < 1 || n > DwBfMulti::MAXP || wb_tot < 1) return hipErrorInvalidValue;
   DwBfMulti m;
   memset(&m, 0, sizeof(m));
@@ -428,6 +469,7 @@ hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base
     if (xks % 2 || !((nit == 10 && !z) || (nit == 9 && z) || (nit == 8 && !z) || (nit == 4 && !z) || (nit == 2 && !z))) return hipErrorInvalidValue;
     a.G[0] = p[i].G; a.X1[0] = p[i].X1; a.X2 = p[i].X2 ? p[i].X2 : p[i].X1; a.ngemm = 1; a.Z = p[i].Z; a.z_tile0 = z ? p[i].x1_ks / 2 : 0;
     a.g_ks = p[i].g_ks; a.o_tiles = (p[i].g_ks + 1) / 2; a.x1_ks = p[i].x1_ks; a.wb_tot = wb_tot; a.slabs = slab;
+    a.gdelta = sp.gdelta; a.xdelta = sp.xdelta;
     m.kind[i] = 2 * nit + (z ? 1 : 0);
     m.wg0[i] = wg0;
     wg0 += nwg[i];
@@ -439,12 +481,20 @@ hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base
   m.wg0[n] = wg0;
   if (slab_end) *slab_end = slab;
   if (slab_limit && slab > slab_limit) return hipErrorOutOfMemory;  // the slabs of this plan would run past the workspace's slab space: nothing is enqueued
-  static std::atomic<unsigned long long> opted{0};
+  static std::atomic<unsigned long long> opted{0}, opted_split{0};
   constexpr int lds_bytes = 144 * 1024;
   static_assert(DwbGeom<10, false>::LDS_BYTES <= lds_bytes && DwbGeom<9, true>::LDS_BYTES <= lds_bytes && DwbGeom<8, false>::LDS_BYTES <= lds_bytes &&
                 DwbGeom<4, false>::LDS_BYTES <= lds_bytes && DwbGeom<2, false>::LDS_BYTES <= lds_bytes, "LDS of the multi-product launch");
-  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_dw_bf16_multi)}, lds_bytes)) return e;
-  hipLaunchKernelGGL(k_dw_bf16_multi, dim3(wg0), dim3(BF_WG), lds_bytes, st, m);
+  static_assert(DwbGeom<10, false, true>::LDS_BYTES <= lds_bytes && DwbGeom<9, true, true>::LDS_BYTES <= lds_bytes && DwbGeom<8, false, true>::LDS_BYTES <= lds_bytes &&
+                DwbGeom<4, false, true>::LDS_BYTES <= 160 * 1024 && DwbGeom<2, false, true>::LDS_BYTES <= 160 * 1024, "LDS of the two-part multi-product launch");
+  if (sp.gdelta || sp.xdelta) {
+    constexpr int lds_split = 160 * 1024;
+    if (hipError_t e = ensure_dynamic_lds(opted_split, {reinterpret_cast<const void*>(&k_dw_bf16_multi<true>)}, lds_split)) return e;
+    hipLaunchKernelGGL(k_dw_bf16_multi<true>, dim3(wg0), dim3(BF_WG), lds_split, st, m);
+    return hipGetLastError();
+  }
+  if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_dw_bf16_multi<false>)}, lds_bytes)) return e;
+  hipLaunchKernelGGL(k_dw_bf16_multi<false>, dim3(wg0), dim3(BF_WG), lds_bytes, st, m);
   return hipGetLastError();
 }
 

@@ -1,4 +1,5 @@
 // field_bwd_split.hip -- backward dX chain of the split-fp32 TRAIN step (NERF_HIP_SPLIT_MLP | NERF_HIP_SAVE_FOR_BACKWARD), MI355X / gfx950.
+// (forward: field_fwd_split.hip<SAVE>; weight gradients: the SPLIT instantiations of dw_bf16.hip)
 //
 // field_bwd_bf16.hip with every fp32 operand written as hi + mid (two bf16 parts, field_fwd_split.hip): the stream holds the TRANSPOSED
 // weights from the colour head back to layer 0 as (hi, mid) fragment pairs, a wave owns 32 samples, and the fp32 accumulator of "d input" of

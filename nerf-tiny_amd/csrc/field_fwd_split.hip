@@ -10,7 +10,7 @@
 // arithmetic in the build container: 3.3e-6 / 2.2e-5) -- the 1e-4 bar is met with the same margin, because what limits both is the
 // conditioning of the fine pass, not the sixteenth bit of a product.  It is an OPT-IN mode (NERF_HIP_SPLIT_MLP, model.split_mlp /
 // model.split_train): the default path keeps the exact k-ordered fp32 fma chains.
-// SAVE (NERF_HIP_SPLIT_MLP | NERF_HIP_SAVE_FOR_BACKWARD: the split-fp32 TRAIN step, field_bwd_split.hip + dw_bf16.hip): every layer input
+// SAVE (NERF_HIP_SPLIT_MLP | NERF_HIP_SAVE_FOR_BACKWARD: the split-fp32 TRAIN step, field_bwd_split.hip + dw_bf16.hip's SPLIT form): every layer input
 // is also written to HBM as TWO bf16 fragment-layout tensors -- its hi parts and its mid parts, each in the layout of the bf16-MLP variant's
 // save buffer (bf16_common.h: 1-KiB pieces, one per wave and k-step, whole lines per store) -- with the ReLU masks of the bf16 layout and the
 // sigma pre-activation; a layer's 2 x 16 pieces + its mask words go out in one burst behind the layer's last tile.

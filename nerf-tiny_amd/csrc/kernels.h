@@ -154,7 +154,6 @@ size_t split_image_bytes();
 // split-fp32 training (field_bwd_split.hip): the transposed image of the backward chain, hi and mid fragment of every step interleaved
 size_t split_bwd_image_bytes();
 hipError_t launch_pack_weights_split_bwd(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
-constexpr int SPLIT_GRAD_SET_FLOATS = 600064;  // one set of the 24 gradient tensors, every tensor padded to 64 floats (>= 593,924 + 24 * 63)
 hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 hipError_t launch_field_fwd_split(const FieldArgs& a, bool save, hipStream_t st);  // save: + hi / mid fragment-layout saves, masks, spre (FieldArgs bsave / bsave2 / bmask)
 hipError_t launch_rays(const RaysArgs& a, hipStream_t st);
@@ -308,10 +307,13 @@ hipError_t launch_field_bwd_reg(const FieldBwdArgs& a, bool fine, hipStream_t st
 hipError_t launch_field_bwd_bf16(const FieldBwdArgs& a, bool fine, hipStream_t st, const BwdFuse* fuse = nullptr);
 hipError_t launch_pack_weights_bf16_bwd(const Weights24& w, const float* fold, unsigned char* img, hipStream_t st);
 size_t dw_bf16_slab_floats();
+// split-fp32 train step: every operand tensor is a (hi, mid) pair of the same layout -- the mid part of a gradient-type tensor (G, Z) lies
+// gdelta bytes behind its hi part, the mid part of an input tensor xdelta bytes; {0, 0} = plain bf16 operands
+struct DwBfSplit { long long gdelta = 0, xdelta = 0; };
 hipError_t launch_dw_bf16_gemm(const unsigned char* G, int g_ks, const unsigned char* X1, int x1_ks, const unsigned char* X2, int x2_ks,
-                               const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st);
+                               const unsigned char* Z, int wb_tot, float* slabs, int* nslab, hipStream_t st, DwBfSplit sp = DwBfSplit{});
 hipError_t launch_dw_bf16_group(const unsigned char* const* Gs, const unsigned char* const* Xs, int n, int wb_tot, float* slabs, int* nslab,
-                                hipStream_t st);
+                                hipStream_t st, DwBfSplit sp = DwBfSplit{});
 // one product of a multi-product launch (small batches: dw_bf16.hip): inputs G, X1 (+ X2) (+ Z); slabs / nslab are filled in
 struct DwBfProd {
   const unsigned char* G; int g_ks;
@@ -321,7 +323,8 @@ struct DwBfProd {
   float* slabs; int nslab;
 };
 // slab_limit: one past the slab space (checked on the host BEFORE the launch: hipErrorOutOfMemory, nothing enqueued) or null
-hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, const float* slab_limit, float** slab_end, hipStream_t st);
+hipError_t launch_dw_bf16_multi(DwBfProd* p, int n, int wb_tot, float* slab_base, const float* slab_limit, float** slab_end, hipStream_t st,
+                                DwBfSplit sp = DwBfSplit{});
 hipError_t launch_dw_bf16_reduce(const float* slabs, int nslab, int rows, int ni, int o_first, int o_count, int i_first, int i_count,
                                  float* dW, int ldw, int col0, float* db, hipStream_t st);
 // dW[o][col0 + i - i_first] = sum over slabs of row o_first + o, column i; db[o] likewise from the last slab column
@@ -366,22 +369,6 @@ struct GatherArgs {
 };
 
 hipError_t launch_adam(const AdamArgs& a, hipStream_t st);
-
-// split-fp32 train step: the three gradient sets of the hi x hi, hi x mid and mid x hi weight-gradient passes -> one (train_ops.hip).
-// out[t] += a[t] + b[t] for the weights, out[t] += b[t] for the biases (bit t of bias_mask: pass `a` = G_hi x X_mid carries the column sums of
-// G_hi a second time); m0 += m1 + m2 for the folded product's M.  Fixed order: deterministic.
-struct SplitSumArgs {
-  float* out[24];
-  const float* a[24];
-  const float* b[24];
-  int numel[24];
-  unsigned bias_mask;
-  float* m0;
-  const float* m1;
-  const float* m2;
-  int m_numel;
-};
-hipError_t launch_split_grad_sum(const SplitSumArgs& a, hipStream_t st);
 hipError_t launch_gather_rays(const GatherArgs& a, hipStream_t st);
 
 }  // namespace nerf

@@ -48,23 +48,6 @@ __global__ __launch_bounds__(256) void k_gather_rays(const GatherArgs a) {
   for (int k = 0; k < 17; ++k) a.poses_bound[(size_t)i * 17 + k] = pr[k];
 }
 
-__global__ __launch_bounds__(256) void k_split_grad_sum(const SplitSumArgs a) {
-  const int t = blockIdx.y;
-  if (t < 24) {
-    float* __restrict__ o = a.out[t];
-    const float* __restrict__ x = a.a[t];
-    const float* __restrict__ y = a.b[t];
-    const bool bias = (a.bias_mask >> t) & 1u;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.numel[t]; i += gridDim.x * 256) o[i] = bias ? o[i] + y[i] : (o[i] + x[i]) + y[i];
-  } else {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m_numel; i += gridDim.x * 256) a.m0[i] = (a.m0[i] + a.m1[i]) + a.m2[i];
-  }
-}
-
-hipError_t launch_split_grad_sum(const SplitSumArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_split_grad_sum, dim3(32, 25), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
 hipError_t launch_adam(const AdamArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_adam, dim3(64, 24), dim3(256), 0, st, a);
   return hipGetLastError();

@@ -75,7 +75,7 @@ class ResampleIndexError(RuntimeError):
 def _call_flags(model, need_grad: bool) -> int:
     bf16 = getattr(model, "bf16_mlp", False)
     # split-fp32: `split_mlp` selects it for inference calls; `split_train` (its own opt-in switch) for TRAINING calls -- forward, dX chain and
-    # weight-gradient products on bf16 MFMA with two-part operands (csrc/field_fwd_split.hip, field_bwd_split.hip, dw_bf16.hip x 3)
+    # weight-gradient products on bf16 MFMA with two-part operands (csrc/field_fwd_split.hip, field_bwd_split.hip, dw_bf16.hip's SPLIT form)
     split = (getattr(model, "split_train", False) and not model.force_tile_kernel) if need_grad else getattr(model, "split_mlp", False)
     return ((_abi.SAVE_FOR_BACKWARD if need_grad else 0) | (_abi.FORCE_TILE_KERNEL if model.force_tile_kernel else 0)
             | (_abi.BF16_MLP if bf16 else 0) | (_abi.CORRECTED if getattr(model, "corrected", False) else 0)
