@@ -309,7 +309,8 @@ hipError_t launch_field_bwd_split(const FieldBwdArgs& a, bool fine, hipStream_t 
   if (hipError_t e = ensure_dynamic_lds(opted, {reinterpret_cast<const void*>(&k_field_bwd_split<false>), reinterpret_cast<const void*>(&k_field_bwd_split<true>)},
                                         SPB_LDS_BYTES))
     return e;
-  const int wgs = (a.M + SPB_WG / 2 - 1) / (SPB_WG / 2);
+  // (whole 256-sample groups of wave blocks, like the forward: every wave block the weight-gradient products read gets its -- zero -- gradients)
+  const int wgs = ((a.M + SPB_WG / 2 - 1) / (SPB_WG / 2) + 1) / 2 * 2;
   if (fine)
     hipLaunchKernelGGL(k_field_bwd_split<true>, dim3(wgs), dim3(SPB_WG), SPB_LDS_BYTES, st, a);
   else

@@ -343,7 +343,11 @@ hipError_t launch_pack_weights_split(const Weights24& w, const float* fold, unsi
 
 hipError_t launch_field_fwd_split(const FieldArgs& a, bool save, hipStream_t st) {
   static std::atomic<unsigned long long> opted{0}, opted_save{0};
-  const int wgs = (a.M + SP_WG / 2 - 1) / (SP_WG / 2);
+  int wgs = (a.M + SP_WG / 2 - 1) / (SP_WG / 2);
+  // training: the fragment-layout buffers count wave blocks in whole 256-sample groups (api.hip wave_blocks); EVERY one of them is read by the
+  // weight-gradient products, so every one is written -- an odd workgroup count gets a trailing workgroup of lanes past the end (copies of the
+  // last sample forward, exact zeros in the chain's gradients)
+  if (save) wgs = (wgs + 1) / 2 * 2;
   if (save) {
     if (!a.bsave || !a.bsave2 || !a.bmask || !a.spre) return hipErrorInvalidValue;
     if (hipError_t e = ensure_dynamic_lds(opted_save, {reinterpret_cast<const void*>(&k_field_fwd_split<true>)}, BF_LDS_BYTES)) return e;
