@@ -406,7 +406,8 @@ def rooflines(leg, prof, b_local, steps):
         wb = ((b_local * NC + 255) // 256 + (b_local * NF + 255) // 256) * 8
         dw_bytes = 2 * DW_BF16_KIB_PER_WAVE_BLOCK * 1024 * wb
         dw = {"bound": "hbm", "achieved": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1) if dw_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-              "frac": round(dw_bytes / (dw_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if dw_ms > 0 else 0.0, "traffic": None, "traffic_source": src,
+              "frac": round(dw_bytes / (dw_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if dw_ms > 0 else 0.0,
+              "traffic": scaled(read_traffic(leg, list(DW_SPLIT_LAUNCHES), scale=DW_SPLIT_LAUNCHES)), "traffic_source": src,
               "kernel": "k_dw_bf16<.., SPLIT> (the weight-gradient products over two-part operands, one pass + the slab reduce)",
               "avg_launch_ms": round(dw_ms, 4), "launches": prof.get("bwd_dw", (0.0, 0))[1], "bytes_per_launch": dw_bytes}
         for blk in (fwd, chain):
@@ -469,7 +470,9 @@ DW_LAUNCHES = {"k_dw4_group": 1, "k_dw4<4, true>": 1, "k_dw4<2, false>": 2, "k_d
                "k_dir_prep": 1, "k_dir_gamma_part": 1, "k_dir_gamma_final": 1}
 # bf16-MLP variant (dw_bf16.hip), 4096 rays: the six 256 x 256 products in one launch, the products with small blocks (layer 4, layer 0, the
 # folded product with the sigma head, the colour head) in another (k_dw_bf16_multi), ONE launch for all slab sums, the fold's gradient kernel
-DW_BF16_LAUNCHES = {"k_dw_bf16<8, false>": 1, "k_dw_bf16_multi": 1, "k_dw_bf16_reduce_batch": 1, "k_fold_grads": 1}
+DW_BF16_LAUNCHES = {"k_dw_bf16<8, false, false>": 1, "k_dw_bf16_multi<false>": 1, "k_dw_bf16_reduce_batch": 1, "k_fold_grads": 1}
+# the split-fp32 train step: the same products in their two-part instantiations
+DW_SPLIT_LAUNCHES = {"k_dw_bf16<8, false, true>": 1, "k_dw_bf16_multi<true>": 1, "k_dw_bf16_reduce_batch": 1, "k_fold_grads": 1}
 DW_BF16_KIB_PER_WAVE_BLOCK = 280  # G and X pieces of bf16_common.h over the products (142 + 138 KiB)
 
 

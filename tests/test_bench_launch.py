@@ -59,6 +59,12 @@ def test_train_traffic_lookup_matches_the_shipped_kernel_names():
     for keys in (["k_field_fwd_bf16<true, 8>"], ["k_field_bwd_bf16<true, 8>", "k_field_bwd_bf16<false, 8>"]):
         assert bench.read_traffic(bf_train, keys) is not None, keys
     assert bench.read_traffic(bf_fwd, ["k_field_fwd_bf16x<2, 8>"]) is not None
+    # the split-fp32 train step's blocks (profiles/r05_train_split_pmc.json)
+    sp_train = bench.Leg("st", True, False, True)
+    ts = bench.read_traffic(sp_train, list(bench.DW_SPLIT_LAUNCHES), scale=bench.DW_SPLIT_LAUNCHES)
+    assert ts is not None and 10e9 < ts < 20e9, ts  # 14.6 GB per step measured
+    for keys in (["k_field_fwd_split<true>"], ["k_field_bwd_split<true>", "k_field_bwd_split<false>"]):
+        assert bench.read_traffic(sp_train, keys) is not None, keys
 
 
 def _bench_module():
