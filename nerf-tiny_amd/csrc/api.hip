@@ -354,7 +354,7 @@ int forward_impl(const float* const* weights24, const int64_t* row, const int64_
   const bool bf16x = bf16 && !save && !(flags & NERF_HIP_FORCE_TILE_KERNEL);
   // split-fp32 inference (field_fwd_split.hip): fp32 operands as two bf16 parts, three bf16 MFMAs per product
   const bool split = (flags & NERF_HIP_SPLIT_MLP) && !bf16;
-  // (split && save: the opt-in split-fp32 TRAIN step -- forward with hi / mid fragment-layout saves, field_bwd_split.hip, three bf16 weight-gradient passes)
+  // (split && save: the opt-in split-fp32 TRAIN step -- forward with hi / mid fragment-layout saves, field_bwd_split.hip, the two-part weight-gradient products)
   const Weights24 w = as_w24(weights24);
 
   ProfChain pc;  // the phases below follow each other with nothing in between
@@ -576,7 +576,7 @@ int backward_impl(const float* const* weights24, const float* dC_coarse, const f
   if (!dC_coarse || !dC_fine || !ws) return fail(NERF_HIP_ERR_ARG, "null argument");
   if (!(flags & NERF_HIP_SAVE_FOR_BACKWARD)) return fail(NERF_HIP_ERR_ARG, "backward needs a forward run with NERF_HIP_SAVE_FOR_BACKWARD");
   const bool bf16 = (flags & NERF_HIP_BF16_MLP) != 0;
-  const bool split = (flags & NERF_HIP_SPLIT_MLP) && !bf16;  // split-fp32 train step: field_bwd_split.hip + three bf16 weight-gradient passes
+  const bool split = (flags & NERF_HIP_SPLIT_MLP) && !bf16;  // split-fp32 train step: field_bwd_split.hip + the two-part weight-gradient products
   const WsLayout L = layout(B, Nc, Nf, flags);
   if (ws_bytes < L.total) return fail(NERF_HIP_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.total);
   if (int rc = check_device()) return rc;
