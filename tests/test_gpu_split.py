@@ -220,3 +220,22 @@ def test_split_train_step_on_ragged_sizes(oracle, pkg, dev, B, Nc, Nf):
     Dc, Df, loss = m.train_step(row, col, pb, K, Ct)
     _, _, ol, _ = oracle.loss_and_grads(w, row, col, pb, K, Ct, Nc, Nf)
     assert abs(float(loss) - float(ol)) <= 1e-5 * float(ol) and all(torch.isfinite(q.grad).all() for q in m.network.parameters())
+
+
+def test_split_train_step_is_bit_reproducible(oracle, pkg, dev):
+    """Like the exact step (tests/test_gpu_backward.py::test_train_step_is_bit_reproducible): every sum of the split-fp32 train step runs in a fixed
+    order (slab reduce in workgroup order, no float atomics) -- the same weights and batch give the same loss and 24 gradients bit for bit."""
+    g = load_golden("cfg1_lego_crop32")
+    row, col, pb, K, Ct = golden_inputs(g)
+    w, m = _model(pkg, oracle, g, dev, row.shape[0])
+    m.split_train = True
+    ref = None
+    for rep in range(3):
+        Cc, Cf, loss = m.train_step(row, col, pb, K, Ct)
+        cur = (float(loss), [p.grad.detach().clone() for p in m.network.parameters()])
+        if ref is None:
+            ref = cur
+            continue
+        assert cur[0] == ref[0]
+        for (k, _), a, b in zip(m.network.named_parameters(), cur[1], ref[1]):
+            assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
